@@ -1,0 +1,280 @@
+"""CPU oracle for the exact-GP hot path (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+**PARITY UNPINNED.**  The arithmetic of the reference's hot path lives in the
+third-party packages ``gpytorch`` / ``linear_operator`` (unpinned in
+``/root/reference/pyproject.toml:32``, not vendored, not installed here, no
+network).  The reference's own tests hold no golden value for an SM-kernel
+entry, an MLL or a gradient (``/root/reference/tests/tests.py:1137-1144`` are
+empty).  This file is therefore a dense fp64 *restatement of GPyTorch's published
+algorithm* with ``gpytorch.settings.fast_computations(False, False, False)``
+(the Cholesky semantics pgmuvi itself selects at ``pgmuvi/lightcurve.py:5966``),
+pinned only by independent known-answer checks that exist in this container
+(``torch.distributions.MultivariateNormal.log_prob``, ``torch.autograd.gradcheck``,
+closed form vs autograd, analytic limits of the kernel).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product package ``pgmuvi_amd`` never does.
+
+Call sites in the reference that this restates:
+
+* ``pgmuvi/gps.py:205-220`` -- ``SpectralMixtureGPModel``: ``ConstantMean`` +
+  ``SpectralMixtureKernel(num_mixtures=Q)``; ``forward`` = ``MVN(mean(x), covar(x))``.
+* ``pgmuvi/gps.py:302-318`` -- 2-D variant, ``SMK(ard_num_dims=2, ...)``.
+* ``pgmuvi/lightcurve.py:2778-2807`` -- noise = ``yerr**2`` vector
+  (``FixedNoiseGaussianLikelihood``) or a learned scalar (``GaussianLikelihood``).
+* ``pgmuvi/trainers.py:119,179-181`` -- ``ExactMarginalLogLikelihood``; one
+  evaluation = ``output = model(x); loss = -mll(output, y); loss.backward()``.
+* SM-kernel formula: the reference's own documentation, comparison notebook
+  "Mathematical framework" cell (``docs/source/notebooks/
+  PGMUVI_comparison_with_other_codes.ipynb:56-66``; 2-D product-of-sums form at
+  ``:1592-1596``) and its Fourier dual in ``pgmuvi/lightcurve.py:9481-9533``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple, Dict
+
+import torch
+
+TWO_PI = 2.0 * math.pi
+TWO_PI_SQ = 2.0 * math.pi ** 2
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+# --------------------------------------------------------------------------
+# A7: constraint transforms (GPyTorch semantics; registered by
+# pgmuvi/lightcurve.py:3817-3838, 3883-3932)
+# --------------------------------------------------------------------------
+def softplus(x: torch.Tensor) -> torch.Tensor:
+    return torch.nn.functional.softplus(x)
+
+
+def inv_softplus(y: torch.Tensor) -> torch.Tensor:
+    # y + log(1 - exp(-y)), the stable inverse of log(1 + exp(x))
+    return y + torch.log(-torch.expm1(-y))
+
+
+def positive(raw: torch.Tensor) -> torch.Tensor:
+    return softplus(raw)
+
+
+def greater_than(raw: torch.Tensor, lb: float) -> torch.Tensor:
+    return softplus(raw) + lb
+
+
+def less_than(raw: torch.Tensor, ub: float) -> torch.Tensor:
+    return ub - softplus(-raw)
+
+
+def interval(raw: torch.Tensor, lb: float, ub: float) -> torch.Tensor:
+    return lb + (ub - lb) * torch.sigmoid(raw)
+
+
+# --------------------------------------------------------------------------
+# A1: spectral-mixture kernel matrix
+# --------------------------------------------------------------------------
+def _as_2d(x: torch.Tensor) -> torch.Tensor:
+    return x.unsqueeze(-1) if x.dim() == 1 else x
+
+
+def sm_kernel(
+    x1: torch.Tensor,
+    x2: torch.Tensor,
+    w: torch.Tensor,
+    mu: torch.Tensor,
+    v: torch.Tensor,
+    dim_order: int = 0,
+) -> torch.Tensor:
+    """Dense SM kernel matrix K(x1, x2).
+
+    x1 (N,d) or (N,), x2 (M,d) or (M,), w (Q,), mu (Q,d), v (Q,d).
+    GPyTorch evaluates "scale, then subtract":
+        exp(-2 pi^2 (x1*v - x2*v)^2) * cos(2 pi (x1*mu - x2*mu)),
+    weights the mixtures *per dimension* and then multiplies over dimensions
+    (dim_order=0:  K = prod_d sum_q w_q e_qd c_qd).  dim_order=1 is the other
+    reading found in the reference (``lightcurve.py:9504-9511``):
+    K = sum_q w_q prod_d e_qd c_qd.  For d=1 they coincide.
+    """
+    x1 = _as_2d(x1)
+    x2 = _as_2d(x2)
+    Q = w.shape[0]
+    d = x1.shape[-1]
+    mu = mu.reshape(Q, d)
+    v = v.reshape(Q, d)
+    x1e = x1.unsqueeze(0) * v.unsqueeze(1)      # (Q,N,d)
+    x2e = x2.unsqueeze(0) * v.unsqueeze(1)      # (Q,M,d)
+    x1c = x1.unsqueeze(0) * mu.unsqueeze(1)
+    x2c = x2.unsqueeze(0) * mu.unsqueeze(1)
+    e = torch.exp(-TWO_PI_SQ * (x1e.unsqueeze(2) - x2e.unsqueeze(1)) ** 2)  # (Q,N,M,d)
+    c = torch.cos(TWO_PI * (x1c.unsqueeze(2) - x2c.unsqueeze(1)))
+    res = e * c
+    if dim_order == 0:
+        return (res * w.view(Q, 1, 1, 1)).sum(0).prod(-1)
+    return (res.prod(-1) * w.view(Q, 1, 1)).sum(0)
+
+
+# --------------------------------------------------------------------------
+# A3 + A4: K + noise, Cholesky, per-datum marginal log-likelihood
+# --------------------------------------------------------------------------
+def _noise_diag(noise: torch.Tensor, n: int) -> torch.Tensor:
+    noise = torch.as_tensor(noise)
+    if noise.dim() == 0 or noise.numel() == 1:
+        return noise.reshape(()).expand(n)
+    return noise.reshape(n)
+
+
+def mll(
+    x: torch.Tensor,
+    y: torch.Tensor,
+    mean: torch.Tensor,
+    noise: torch.Tensor,
+    w: torch.Tensor,
+    mu: torch.Tensor,
+    v: torch.Tensor,
+    dim_order: int = 0,
+    jitter: float = 0.0,
+) -> torch.Tensor:
+    """ExactMarginalLogLikelihood value:  log N(y | mean, K + diag(noise)) / N.
+
+    ``mean`` is the length-N mean vector (or a scalar); ``noise`` a length-N
+    vector (FixedNoise) or a scalar (GaussianLikelihood).
+    """
+    x2 = _as_2d(x)
+    n = x2.shape[0]
+    K = sm_kernel(x2, x2, w, mu, v, dim_order)
+    A = K + torch.diag_embed(_noise_diag(noise, n) + jitter)
+    L = torch.linalg.cholesky(A)
+    r = (y - mean).reshape(n, 1)
+    z = torch.linalg.solve_triangular(L, r, upper=False)
+    inv_quad = (z * z).sum()
+    logdet = 2.0 * torch.log(torch.diagonal(L)).sum()
+    return -0.5 * (inv_quad + logdet + n * LOG_2PI) / n
+
+
+def mll_value_grad_autograd(x, y, mean, noise, w, mu, v, dim_order=0, jitter=0.0):
+    """Value + gradients by torch.autograd through the dense graph (what
+    ``loss.backward()`` at ``pgmuvi/trainers.py:181`` does, sign of +mll)."""
+    n = _as_2d(x).shape[0]
+    mean_v = torch.as_tensor(mean, dtype=x.dtype).expand(n).clone().requires_grad_(True)
+    noise_t = torch.as_tensor(noise, dtype=x.dtype)
+    noise_v = noise_t.clone().requires_grad_(True)
+    w_ = w.clone().requires_grad_(True)
+    mu_ = mu.clone().requires_grad_(True)
+    v_ = v.clone().requires_grad_(True)
+    val = mll(x, y, mean_v, noise_v, w_, mu_, v_, dim_order, jitter)
+    g = torch.autograd.grad(val, [w_, mu_, v_, noise_v, mean_v])
+    return val.detach(), dict(w=g[0], mu=g[1], v=g[2], noise=g[3], mean=g[4])
+
+
+def mll_value_grad_closed_form(x, y, mean, noise, w, mu, v, dim_order=0, jitter=0.0):
+    """Value + gradients by the closed form:
+
+        alpha = A^-1 r,  G = alpha alpha^T - A^-1,
+        d mll / d theta = (1/2N) sum_ij G_ij dK_ij/d theta,
+        d mll / d noise_i = G_ii / (2N),   d mll / d mean = alpha / N.
+    """
+    with torch.no_grad():
+        x2 = _as_2d(x)
+        n, d = x2.shape
+        Q = w.shape[0]
+        mu2 = mu.reshape(Q, d)
+        v2 = v.reshape(Q, d)
+        tau = x2.unsqueeze(1) - x2.unsqueeze(0)                     # (N,N,d) unscaled
+        xs = x2.unsqueeze(0) * v2.unsqueeze(1)
+        xc = x2.unsqueeze(0) * mu2.unsqueeze(1)
+        ds = xs.unsqueeze(2) - xs.unsqueeze(1)                      # (Q,N,N,d)
+        dc = TWO_PI * (xc.unsqueeze(2) - xc.unsqueeze(1))
+        e = torch.exp(-TWO_PI_SQ * ds ** 2)
+        c = torch.cos(dc)
+        s = torch.sin(dc)
+        wq = w.view(Q, 1, 1, 1)
+        if dim_order == 0:
+            S = (wq * e * c).sum(0)                                 # (N,N,d)
+            K = S.prod(-1)
+        else:
+            P = (e * c).prod(-1)                                    # (Q,N,N)
+            K = (w.view(Q, 1, 1) * P).sum(0)
+        nd = _noise_diag(torch.as_tensor(noise, dtype=x2.dtype), n)
+        A = K + torch.diag_embed(nd + jitter)
+        L = torch.linalg.cholesky(A)
+        r = (y - torch.as_tensor(mean, dtype=x2.dtype).expand(n)).reshape(n, 1)
+        z = torch.linalg.solve_triangular(L, r, upper=False)
+        val = -0.5 * ((z * z).sum() + 2.0 * torch.log(torch.diagonal(L)).sum() + n * LOG_2PI) / n
+        alpha = torch.cholesky_solve(r, L)
+        Ainv = torch.cholesky_inverse(L)
+        G = alpha @ alpha.T - Ainv
+        half_n = 0.5 / n
+
+        def others(T, k):  # product of T[..., k'] over k' != k
+            out = torch.ones_like(T[..., 0])
+            for kk in range(T.shape[-1]):
+                if kk != k:
+                    out = out * T[..., kk]
+            return out
+
+        g_w = torch.zeros_like(w)
+        g_mu = torch.zeros_like(mu2)
+        g_v = torch.zeros_like(v2)
+        for k in range(d):
+            dmu_k = -TWO_PI * tau[..., k] * wq[..., 0] * e[..., k] * s[..., k]           # (Q,N,N)
+            dv_k = -2.0 * TWO_PI_SQ * v2[:, k].view(Q, 1, 1) * tau[..., k] ** 2 * wq[..., 0] * e[..., k] * c[..., k]
+            if dim_order == 0:
+                oth = others(S, k).unsqueeze(0)                     # (1,N,N)
+                g_w += half_n * (G.unsqueeze(0) * oth * e[..., k] * c[..., k]).sum((1, 2))
+            else:
+                oth = others(e * c, k)                              # (Q,N,N)
+            g_mu[:, k] = half_n * (G.unsqueeze(0) * oth * dmu_k).sum((1, 2))
+            g_v[:, k] = half_n * (G.unsqueeze(0) * oth * dv_k).sum((1, 2))
+        if dim_order != 0:
+            g_w = half_n * (G.unsqueeze(0) * P).sum((1, 2))
+        g_noise_vec = half_n * torch.diagonal(G)
+        noise_t = torch.as_tensor(noise)
+        g_noise = g_noise_vec.sum().reshape(noise_t.shape) if noise_t.numel() == 1 else g_noise_vec.reshape(noise_t.shape)
+        g_mean = (alpha / n).reshape(n)
+        return val, dict(w=g_w, mu=g_mu.reshape(mu.shape), v=g_v.reshape(v.shape), noise=g_noise, mean=g_mean)
+
+
+# --------------------------------------------------------------------------
+# section 8f row 1: posterior prediction (eval mode), dense Cholesky semantics
+# (pgmuvi/lightcurve.py:9607-9631: likelihood(model(x_test)))
+# --------------------------------------------------------------------------
+def posterior(x, y, mean, noise, w, mu, v, xs, mean_s, dim_order=0, jitter=0.0):
+    """Latent posterior mean and variance at test inputs ``xs``:
+        m* + K*^T alpha,   diag(K** - K*^T A^-1 K*).
+    (The likelihood's predictive adds its noise to the variance on top.)"""
+    x2, xs2 = _as_2d(x), _as_2d(xs)
+    n = x2.shape[0]
+    K = sm_kernel(x2, x2, w, mu, v, dim_order)
+    A = K + torch.diag_embed(_noise_diag(noise, n) + jitter)
+    L = torch.linalg.cholesky(A)
+    r = (y - mean).reshape(n, 1)
+    alpha = torch.cholesky_solve(r, L)
+    Ks = sm_kernel(x2, xs2, w, mu, v, dim_order)                    # (N,M)
+    pm = mean_s + (Ks.T @ alpha).reshape(-1)
+    B = torch.linalg.solve_triangular(L, Ks, upper=False)
+    kss = sm_kernel(xs2[:1], xs2[:1], w, mu, v, dim_order)[0, 0]    # stationary: K(x,x) const
+    pv = kss - (B * B).sum(0)
+    return pm, pv
+
+
+# --------------------------------------------------------------------------
+# section 8d: benchmark hyper-parameters (used by tests and bench cpu_baseline)
+# --------------------------------------------------------------------------
+def cfg_hypers(cfg: int, y: torch.Tensor, dtype=torch.float64) -> Dict[str, torch.Tensor]:
+    """The hyper-parameters SURVEY.md section 8d evaluates the MLL at."""
+    if cfg == 1:
+        w = torch.tensor([1.0], dtype=dtype)
+        mu = torch.tensor([[1.0 / 150.0]], dtype=dtype)
+        v = torch.tensor([[1.0 / 1500.0]], dtype=dtype)
+    elif cfg in (2, 3, 5):
+        amp = torch.tensor([1.0, 0.5, 0.3, 0.2], dtype=dtype)
+        w = amp ** 2 / 2.0
+        mu = (1.0 / torch.tensor([150.0, 67.0, 400.0, 31.0], dtype=dtype)).reshape(4, 1)
+        v = mu / 10.0
+    elif cfg == 4:
+        w = torch.full((3,), 1.0 / 3.0, dtype=dtype)
+        mu = torch.tensor([[1 / 12.5, 0.5], [2 / 12.5, 0.5], [1 / 25.0, 0.5]], dtype=dtype)
+        v = torch.tensor([[0.01, 0.3]] * 3, dtype=dtype)
+    else:
+        raise ValueError(cfg)
+    return dict(w=w, mu=mu, v=v, mean=y.to(dtype).mean())

@@ -1,0 +1,163 @@
+"""CPU tests that pin the oracle (test infrastructure) by independent known answers.
+
+The reference holds no numerical fixture for this path (SURVEY.md section 8c:
+parity UNPINNED at the gpytorch boundary); what can be checked here is that the
+restatement is self-consistent and agrees with torch's own MVN log-prob, with
+autograd/gradcheck, with the analytic limits of the SM kernel and with the
+committed golden files.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sm_mll_oracle as orc
+from pgmuvi_amd import synthetic as syn
+
+D = torch.float64
+
+
+def _load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _problem(golden_dir, tag, cfg):
+    inp = _load(golden_dir, f"inputs_{tag}.npz")
+    x = torch.as_tensor(inp["x"], dtype=D)
+    y = torch.as_tensor(inp["y"], dtype=D)
+    noise = torch.as_tensor(inp["yerr"], dtype=D) ** 2
+    h = syn.cfg_hypers(cfg, y)
+    Q = h["w"].shape[0]
+    return x, y, noise, h["w"], h["mu"].reshape(Q, -1), h["v"].reshape(Q, -1), h["mean"]
+
+
+def test_generators_reproduce_reference_inputs_bit_for_bit(golden_dir):
+    g = _load(golden_dir, "inputs_cfg1.npz")
+    t, y, e = syn.cfg1()
+    assert np.array_equal(t.numpy(), g["x"]) and np.array_equal(y.numpy(), g["y"]) and np.array_equal(e.numpy(), g["yerr"])
+    for n in (64, 200, 512, 4096):
+        g = _load(golden_dir, f"inputs_cfg2_n{n}.npz")
+        t, y, e = syn.cfg2(n_obs=n)
+        assert np.array_equal(t.numpy(), g["x"]) and np.array_equal(y.numpy(), g["y"]) and np.array_equal(e.numpy(), g["yerr"])
+    g = _load(golden_dir, "inputs_cfg4_n256.npz")
+    x, y, e = syn.cfg4(n_per_band=32)
+    assert np.array_equal(x.numpy(), g["x"]) and np.array_equal(y.numpy(), g["y"]) and np.array_equal(e.numpy(), g["yerr"])
+    assert t.dtype == torch.float32 and x.shape == (256, 2)
+
+
+def test_kernel_known_answers():
+    x = torch.linspace(0, 10, 37, dtype=D)
+    w = torch.tensor([0.7, 0.2], dtype=D)
+    mu = torch.tensor([[0.3], [1.1]], dtype=D)
+    v = torch.tensor([[0.05], [0.2]], dtype=D)
+    K = orc.sm_kernel(x, x, w, mu, v)
+    assert torch.allclose(K, K.T, atol=1e-15)
+    assert torch.allclose(torch.diagonal(K), w.sum().expand(37), atol=1e-15)   # K_ii = sum_q w_q
+    assert torch.linalg.eigvalsh(K).min() > -1e-10                              # PSD
+    # Q=1, v -> 0: pure cosine
+    K1 = orc.sm_kernel(x, x, torch.tensor([2.0], dtype=D), torch.tensor([[0.25]], dtype=D), torch.tensor([[0.0]], dtype=D))
+    tau = x[:, None] - x[None, :]
+    assert torch.allclose(K1, 2.0 * torch.cos(2 * math.pi * 0.25 * tau), atol=1e-13)
+    # mu = 0: pure squared-exponential with lengthscale 1/(2 pi v)
+    K2 = orc.sm_kernel(x, x, torch.tensor([1.0], dtype=D), torch.tensor([[0.0]], dtype=D), torch.tensor([[0.1]], dtype=D))
+    ell = 1.0 / (2 * math.pi * 0.1)
+    assert torch.allclose(K2, torch.exp(-0.5 * tau ** 2 / ell ** 2), atol=1e-13)
+
+
+def test_kernel_2d_orders():
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(23, 2, generator=g, dtype=D) * 5
+    w = torch.rand(3, generator=g, dtype=D)
+    mu = torch.rand(3, 2, generator=g, dtype=D)
+    v = torch.rand(3, 2, generator=g, dtype=D) * 0.3
+    K0 = orc.sm_kernel(x, x, w, mu, v, 0)
+    K1 = orc.sm_kernel(x, x, w, mu, v, 1)
+    per_dim = [orc.sm_kernel(x[:, k], x[:, k], w, mu[:, k:k + 1], v[:, k:k + 1]) for k in range(2)]
+    assert torch.allclose(K0, per_dim[0] * per_dim[1], atol=1e-14)             # prod_d sum_q
+    manual = sum(w[q] * orc.sm_kernel(x[:, 0], x[:, 0], torch.ones(1, dtype=D), mu[q:q + 1, :1], v[q:q + 1, :1])
+                 * orc.sm_kernel(x[:, 1], x[:, 1], torch.ones(1, dtype=D), mu[q:q + 1, 1:], v[q:q + 1, 1:]) for q in range(3))
+    assert torch.allclose(K1, manual, atol=1e-14)                               # sum_q prod_d
+    assert not torch.allclose(K0, K1)
+
+
+@pytest.mark.parametrize("tag,cfg", [("cfg1", 1), ("cfg2_n64", 2), ("cfg2_n200", 2), ("cfg4_n256", 4)])
+def test_mll_matches_torch_mvn_log_prob(golden_dir, tag, cfg):
+    x, y, noise, w, mu, v, mean = _problem(golden_dir, tag, cfg)
+    n = y.shape[0]
+    val = orc.mll(x, y, mean, noise, w, mu, v)
+    K = orc.sm_kernel(x, x, w, mu, v)
+    mvn = torch.distributions.MultivariateNormal(mean.expand(n), covariance_matrix=K + torch.diag(noise))
+    assert abs(float(val - mvn.log_prob(y) / n)) < 1e-12
+
+
+@pytest.mark.parametrize("dim_order", [0, 1])
+def test_closed_form_gradient_matches_autograd_and_gradcheck(dim_order):
+    g = torch.Generator().manual_seed(3)
+    n, Q, d = 40, 3, 2
+    x = torch.rand(n, d, generator=g, dtype=D) * 20
+    y = torch.randn(n, generator=g, dtype=D)
+    noise = 0.05 + 0.1 * torch.rand(n, generator=g, dtype=D)
+    w = 0.2 + torch.rand(Q, generator=g, dtype=D)
+    mu = torch.rand(Q, d, generator=g, dtype=D) * 0.3
+    v = 0.02 + torch.rand(Q, d, generator=g, dtype=D) * 0.1
+    mean = torch.tensor(0.1, dtype=D)
+    va, ga = orc.mll_value_grad_autograd(x, y, mean, noise, w, mu, v, dim_order)
+    vc, gc = orc.mll_value_grad_closed_form(x, y, mean, noise, w, mu, v, dim_order)
+    assert abs(float(va - vc)) < 1e-13
+    for k in ga:
+        assert torch.allclose(ga[k], gc[k], rtol=1e-9, atol=1e-12), k
+    f = lambda w_, mu_, v_, nz: orc.mll(x, y, mean, nz, w_, mu_, v_, dim_order)
+    args = [t.clone().requires_grad_(True) for t in (w, mu, v, noise)]
+    assert torch.autograd.gradcheck(f, args, eps=1e-6, atol=1e-6, rtol=1e-4)
+
+
+def test_scalar_noise_gradient():
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(30, generator=g, dtype=D) * 50
+    y = torch.randn(30, generator=g, dtype=D)
+    w = torch.tensor([0.5], dtype=D); mu = torch.tensor([[0.1]], dtype=D); v = torch.tensor([[0.01]], dtype=D)
+    noise = torch.tensor(0.3, dtype=D)
+    va, ga = orc.mll_value_grad_autograd(x, y, 0.0, noise, w, mu, v)
+    vc, gc = orc.mll_value_grad_closed_form(x, y, 0.0, noise, w, mu, v)
+    assert torch.allclose(ga["noise"], gc["noise"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2_n64", "cfg2_n200", "cfg2_n512", "cfg4_n256_order0", "cfg4_n256_order1"])
+def test_oracle_reproduces_committed_expectations(golden_dir, name):
+    exp = _load(golden_dir, f"expect_{name}.npz")
+    tag = name.replace("_order0", "").replace("_order1", "")
+    order = 1 if name.endswith("order1") else 0
+    inp = _load(golden_dir, f"inputs_{tag}.npz")
+    x = torch.as_tensor(inp["x"], dtype=D); y = torch.as_tensor(inp["y"], dtype=D)
+    noise = torch.as_tensor(inp["yerr"], dtype=D) ** 2
+    k = 0
+    while f"mll_{k}" in exp:
+        w, mu, v = (torch.as_tensor(exp[f"{p}_{k}"]) for p in ("w", "mu", "v"))
+        val, g = orc.mll_value_grad_closed_form(x, y, torch.as_tensor(exp[f"meanc_{k}"]), noise, w, mu, v, order)
+        assert abs(float(val) - float(exp[f"mll_{k}"])) < 1e-11
+        for p in ("w", "mu", "v", "noise", "mean"):
+            ref = torch.as_tensor(exp[f"g_{p}_{k}"])
+            assert torch.allclose(g[p], ref, rtol=1e-8, atol=1e-12 * float(ref.abs().max()) + 1e-300), (p, k)
+        k += 1
+    assert k >= 1
+
+
+def test_constraint_transforms_roundtrip():
+    raw = torch.linspace(-5, 5, 11, dtype=D)
+    assert torch.allclose(orc.inv_softplus(orc.softplus(raw)), raw, atol=1e-12)
+    assert abs(float(orc.positive(torch.zeros((), dtype=D))) - math.log(2.0)) < 1e-15   # 0.6931 in the reference notebook
+    assert torch.all(orc.greater_than(raw, 1e-4) > 1e-4)
+    assert torch.all(orc.less_than(raw, 3.0) < 3.0)
+    iv = orc.interval(raw, -1.0, 2.0)
+    assert torch.all(iv > -1.0) and torch.all(iv < 2.0)
+
+
+def test_posterior_interpolates_noise_free_limit():
+    x = torch.linspace(0, 30, 50, dtype=D)
+    w = torch.tensor([1.0], dtype=D); mu = torch.tensor([[0.1]], dtype=D); v = torch.tensor([[0.02]], dtype=D)
+    y = torch.sin(2 * math.pi * 0.1 * x)
+    pm, pv = orc.posterior(x, y, torch.zeros((), dtype=D), torch.tensor(1e-8, dtype=D), w, mu, v, x[::7], torch.zeros((), dtype=D))
+    assert torch.allclose(pm, y[::7], atol=1e-4)
+    assert torch.all(pv.abs() < 1e-5)
