@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- marginal-log-likelihood evaluations/sec of the MI355X hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path -- SM kernel build + blocked Cholesky MLL + full
+hyper-parameter gradient (pgmuvi/trainers.py:179-181 without the optimiser step) -- over
+one batch of B synthetic config-2 light curves per GPU (N=4096 points, Q=4 mixtures,
+fp64; default B=1 = BASELINE.json configs[1], "Single 1D Lightcurve").  Inputs are
+resident in HBM before the timed region.  With N>1 GPUs every rank evaluates its own
+light curves (weak scaling, no data-path collective) and one RCCL all_gather of the
+log-likelihoods closes each step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pgmuvi_amd import _hip, synthetic as syn  # noqa: E402
+from pgmuvi_amd.batch import gather_logliks  # noqa: E402
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet "FP64 matrix" (the guides list no fp64 MFMA figure)
+NB = 128
+
+
+def make_batch(n, B, rank, dev):
+    xs, ys, ns, ws, mus, vs, ms = [], [], [], [], [], [], []
+    for b in range(B):
+        t, y, e = syn.cfg2(n_obs=n, seed=2 + 1000 * rank + b)        # rank 0, b 0 == the golden cfg-2 light curve
+        h = syn.cfg_hypers(2, y.double())
+        xs.append(t.double().reshape(n, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+        ws.append(h["w"]); mus.append(h["mu"].reshape(-1, 1)); vs.append(h["v"].reshape(-1, 1)); ms.append(h["mean"].expand(n))
+    st = lambda L: torch.stack(L).to(dev).contiguous()
+    return dict(x=st(xs), y=st(ys), mean=st(ms), noise=st(ns), w=st(ws), mu=st(mus), v=st(vs))
+
+
+def update_flops(n):
+    """Algorithmic flops of the trailing_update launches of one evaluation: every 128^3
+    tile product of  A_ij -= U_ki^T U_kj  (Cholesky) and  R_ij -= U_ki^T V_kj  (inverse
+    factor); together 2 N^3 / 3 of the N^3 per evaluation."""
+    nb = (n + NB - 1) // NB
+    tiles = sum((nb - 1 - k) * (nb - k) // 2 + (nb - 1 - k) * (k + 1) for k in range(nb))
+    return tiles * 2.0 * NB ** 3
+
+
+def cpu_baseline(n, reps):
+    """The oracle (torch-CPU restatement of the reference path, NOT GPyTorch) timed on the
+    host cores: value + gradient by autograd through the dense graph, as loss.backward()
+    does in the reference."""
+    from oracle import sm_mll_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    t, y, e = syn.cfg2(n_obs=n)
+    x64, y64, nz = t.double(), y.double(), e.double() ** 2
+    h = syn.cfg_hypers(2, y64)
+    mu, v = h["mu"].reshape(-1, 1), h["v"].reshape(-1, 1)
+    orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)      # warm-up
+    times = []
+    val = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        val, _g = orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=1.0 / med, unit="evals/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{reps} value+grad evaluations (1 warm-up) of the same N={n} Q=4 light curve, median {med * 1e3:.0f} ms"), float(val)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="light curves per GPU per step")
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the batched / surface side measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    n, B = args.n, args.batch
+    data = make_batch(n, B, rank, dev)
+    ws = _hip.get_workspace(dev, n, 4, 1, B)
+
+    def step(check=False):
+        out = _hip.mll_value_grad(data["x"], data["y"], data["mean"], data["noise"], None, data["w"], data["mu"], data["v"],
+                                  0, 0.0, True, workspace=ws)
+        ll = gather_logliks(out["mll"], B * world)
+        return out, ll
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, ll = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, ll = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    assert int(out["info"].abs().max()) == 0, "factorisation failed inside the timed region"
+    assert ll.numel() == B * world and bool(torch.isfinite(ll).all())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    # ---- per-kernel device time (HIP events on the launch stream), same K steps again
+    ws.profile(True)
+    for _ in range(args.steps):
+        step()
+    prof = ws.profile_read()
+    ws.profile(False)
+    upd_ms, upd_launches = prof["trailing_update"]
+    flops = update_flops(n) * B * args.steps
+    achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    roofline = dict(bound="mfma", kernel="trailing_update (k_update: v_mfma_f64_16x16x4_f64 TN tile GEMM)",
+                    achieved=round(achieved, 3), peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                    avg_launch_us=round(upd_ms / max(upd_launches, 1) * 1e3, 2), launches_per_eval=upd_launches // args.steps,
+                    flops_per_eval=update_flops(n) * B)
+    phases = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+
+    result = None
+    if rank == 0:
+        result = {
+            "metric": "marginal-log-likelihood evals/sec, N=4096 Q=4 SM kernel" if n == 4096 else f"marginal-log-likelihood evals/sec, N={n} Q=4 SM kernel",
+            "value": round(value, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2: 1-D light curve N={n}, Q=4 spectral-mixture exact GP, fp64, value + full gradient, "
+                                   f"{B} light curve(s) per GPU per step", "batch_per_gpu": B, "n": n, "q": 4, "d": 1,
+                       "parallelism": f"independent light curves per GPU x{world}, all_gather of log-liks per step"},
+            "roofline": roofline,
+            "phase_ms_per_step": phases,
+        }
+    extra = {}
+    if world == 1 and not args.no_extra:
+        # measured fp64 MFMA issue rate on this device (context for the datasheet peak)
+        extra["mfma_f64_probe_tflops"] = round(_hip.probe_mfma_f64(local), 2)
+        # throughput mode: 8 light curves share every launch (batch on gridDim.z)
+        B2 = 8
+        d2 = make_batch(n, B2, rank, dev)
+        ws2 = _hip.get_workspace(dev, n, 4, 1, B2)
+        f2 = lambda: _hip.mll_value_grad(d2["x"], d2["y"], d2["mean"], d2["noise"], None, d2["w"], d2["mu"], d2["v"], 0, 0.0, True, workspace=ws2)
+        f2(); torch.cuda.synchronize()
+        k2 = max(2, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            f2()
+        torch.cuda.synchronize()
+        extra["batched"] = {"batch_per_gpu": B2, "evals_per_s": round(B2 * k2 / (time.perf_counter() - t0), 3)}
+        ws = _hip.get_workspace(dev, n, 4, 1, B)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cb, cpu_val = cpu_baseline(n, args.cpu_reps)
+        result["cpu_baseline"] = cb
+        gpu_val = float(out["mll"].reshape(-1)[0])
+        result["parity"] = {"abs_dmll_vs_cpu_oracle": abs(gpu_val - cpu_val), "tolerance": 1e-4, "mll": gpu_val}
+        result["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
+    if rank == 0:
+        result.update(extra)
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+/*
+ * pgmuvi_hip.h -- C ABI of the MI355X (gfx950) exact-GP hot path.
+ *
+ * The reference (ICSM/pgmuvi) has no C / FFI / plugin interface: it reaches this
+ * arithmetic through GPyTorch's Python object protocol.
+ * Each entry point below names the reference call site whose arithmetic it
+ * replaces; the Python shim `pgmuvi_amd.gpytorch` binds them with ctypes (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to row-major, contiguous fp64 data owned
+ *    by the caller, unless the parameter name ends in `_host`;
+ *  - all work is enqueued on the caller's `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream); nothing synchronises the host except the
+ *    functions documented to do so;
+ *  - return value: 0 ok, <0 = -(index of the first bad argument), >0 only from
+ *    pgm_workspace_info (LAPACK-style 1-based index of the first non-positive pivot);
+ *  - no function throws or aborts; a workspace is not re-entrant (one caller
+ *    thread per handle at a time).
+ */
+#ifndef PGMUVI_HIP_H
+#define PGMUVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgm_ws pgm_ws;
+
+/* Library / build identification ("pgmuvi_hip <ver> gfx950"). */
+const char* pgm_version(void);
+
+/* Largest Q*d the kernels are built for (LDS staging of per-point factors). */
+int pgm_max_qd(void);
+
+/*
+ * Workspace: every device buffer the path needs for `max_batch` simultaneous
+ * problems of up to `max_n` points (factor matrix, diagonal-block inverses,
+ * per-point factors, partial sums).  Allocated once, reused by every call.
+ * `max_d` in {1,2}; `max_q * max_d <= pgm_max_qd()`.
+ */
+int pgm_workspace_create(pgm_ws** ws, int device, int64_t max_n, int max_q, int max_d, int max_batch);
+int pgm_workspace_destroy(pgm_ws* ws);
+size_t pgm_workspace_bytes(const pgm_ws* ws);
+
+/*
+ * Dense spectral-mixture kernel matrix  K[i,j] = k(x1_i, x2_j)  (n1 x n2, leading
+ * dimension ldk), optionally + diag(noise) (+ noise_scalar) when x1 == x2.
+ * Replaces gpytorch SpectralMixtureKernel.forward as constructed at
+ * pgmuvi/gps.py:208 (1-D) and :305 (ard_num_dims=2), i.e. `covar_module(x)`
+ * at gps.py:219, and `kernel(x, x).to_dense()` (tests/test_kernels.py:41).
+ *   w (Q), mu (Q x d), v (Q x d);  dim_order 0 = prod_d sum_q (GPyTorch),
+ *   1 = sum_q prod_d.   noise may be NULL.
+ */
+int pgm_sm_kernel_f64(const double* x1, int64_t n1, const double* x2, int64_t n2, int d,
+                      const double* w, const double* mu, const double* v, int q,
+                      const double* noise, double noise_scalar, int dim_order,
+                      double* K, int64_t ldk, void* stream);
+
+/*
+ * One marginal-log-likelihood evaluation, value (+ gradient when need_grad):
+ * the arithmetic behind `output = model(train_x); loss = -mll(output, train_y);
+ * loss.backward()` at pgmuvi/trainers.py:179-181, i.e. rows A1+A3+A4+A5 of
+ * SURVEY.md section 8a (SM kernel build, + noise, blocked Cholesky, log-det,
+ * inverse quadratic form, closed-form gradient) with GPyTorch's
+ * fast_computations(False, False, False) semantics (pgmuvi/lightcurve.py:5966).
+ *
+ *   x (n x d), y (n), mean (n): mean-module output m(x);
+ *   noise (n) fixed/heteroscedastic variances (FixedNoiseGaussianLikelihood,
+ *   pgmuvi/lightcurve.py:2778-2789) or NULL, plus noise_scalar added to every
+ *   diagonal entry (GaussianLikelihood's learned sigma^2, lightcurve.py:2807);
+ *   jitter is added to the diagonal too (psd_safe_cholesky retry policy lives in
+ *   the caller).
+ * Outputs (device):
+ *   mll[1]      log N(y | mean, K + noise) / n            (already divided by n)
+ *   g_w[q], g_mu[q*d], g_v[q*d]   d mll / d (weights, means, scales)
+ *   g_noise[n]  d mll / d noise_i  (sum it for the scalar noise)
+ *   g_mean[n]   d mll / d mean_i   (= alpha / n)
+ *   info[1]     0, or 1-based index of the first non-positive pivot (then the
+ *               other outputs are undefined, as with LAPACK potrf).
+ * Gradient outputs may be NULL when need_grad == 0.
+ */
+int pgm_mll_value_grad_f64(pgm_ws* ws, const double* x, const double* y, const double* mean,
+                           const double* noise, double noise_scalar, int64_t n, int d,
+                           const double* w, const double* mu, const double* v, int q,
+                           int dim_order, double jitter, int need_grad,
+                           double* mll, double* g_w, double* g_mu, double* g_v,
+                           double* g_noise, double* g_mean, int* info, void* stream);
+
+/*
+ * The same for `batch` independent light curves of equal n (config 3 / MCMC
+ * chains): every array gains a leading batch dimension (x: batch x n x d, w:
+ * batch x q, ..., mll: batch, info: batch); `noise_scalar` may be NULL or a
+ * device array of `batch` values.  All problems advance together, one launch
+ * per algorithm step with the batch on gridDim.z.
+ */
+int pgm_mll_value_grad_batched_f64(pgm_ws* ws, int batch,
+                                   const double* x, const double* y, const double* mean,
+                                   const double* noise, const double* noise_scalar, int64_t n, int d,
+                                   const double* w, const double* mu, const double* v, int q,
+                                   int dim_order, double jitter, int need_grad,
+                                   double* mll, double* g_w, double* g_mu, double* g_v,
+                                   double* g_noise, double* g_mean, int* info, void* stream);
+
+/*
+ * Posterior prediction at n_test inputs from the factor left in the workspace by
+ * the last pgm_mll_value_grad_f64 call with need_grad != 0 (alpha and
+ * L^-1 are kept):  mean_out = mean_test + K*^T alpha,
+ *                  var_out  = k(x*,x*) - || L^-1 K* ||^2   (latent variance).
+ * Replaces `likelihood(model(x_test))` in eval mode at
+ * pgmuvi/lightcurve.py:9607-9631, 9862, 9937, 10071.
+ */
+int pgm_predict_f64(pgm_ws* ws, const double* x_test, const double* mean_test, int64_t n_test,
+                    double* mean_out, double* var_out, void* stream);
+
+/*
+ * Per-kernel device timing (HIP events on `stream`), for bench.py's roofline
+ * block.  While enabled every launch of the named phase is bracketed by events;
+ * pgm_profile_read synchronises the stream and returns accumulated milliseconds
+ * and launch counts per phase (arrays of pgm_profile_phases() entries; names from
+ * pgm_profile_phase_name).  Disabled by default (no overhead).
+ */
+int pgm_profile_enable(pgm_ws* ws, int on);
+int pgm_profile_phases(void);
+const char* pgm_profile_phase_name(int phase);
+int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
+
+/* fp64 MFMA issue-rate probe (TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on
+ * every CU); used once by bench.py to report the measured peak beside the
+ * datasheet figure.  Synchronises. */
+int pgm_probe_mfma_f64(int device, double* tflops_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGMUVI_HIP_H */

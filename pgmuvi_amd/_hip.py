@@ -1,0 +1,263 @@
+"""ctypes binding of ``libpgmuvi_hip.so`` (the C ABI in ``include/pgmuvi_hip.h``).
+
+There is NO CPU fallback: if the shared library is missing, or a tensor is not on
+an MI355X device, the calls raise.  PyTorch is used only for device memory and
+streams; every pointer handed to the library is a plain device address.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p, POINTER, byref
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpgmuvi_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+# name -> (restype, argtypes); must list every symbol of include/pgmuvi_hip.h
+SYMBOLS = {
+    "pgm_version": (c_char_p, []),
+    "pgm_max_qd": (c_int, []),
+    "pgm_workspace_create": (c_int, [POINTER(c_void_p), c_int, c_int64, c_int, c_int, c_int]),
+    "pgm_workspace_destroy": (c_int, [c_void_p]),
+    "pgm_workspace_bytes": (c_size_t, [c_void_p]),
+    "pgm_sm_kernel_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
+    "pgm_mll_value_grad_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pgm_mll_value_grad_batched_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double,
+                                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
+    "pgm_predict_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "pgm_profile_enable": (c_int, [c_void_p, c_int]),
+    "pgm_profile_phases": (c_int, []),
+    "pgm_profile_phase_name": (c_char_p, [c_int]),
+    "pgm_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    "pgm_probe_mfma_f64": (c_int, [c_int, POINTER(c_double)]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the library and declare every prototype (no GPU call is made)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise HipLibraryMissing(
+                    f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  pgmuvi_amd has no CPU fallback.")
+            lib = ctypes.CDLL(_LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def version() -> str:
+    return load().pgm_version().decode()
+
+
+def max_qd() -> int:
+    return int(load().pgm_max_qd())
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with status {rc} (negative = index of the bad argument, see include/pgmuvi_hip.h)")
+
+
+def _dev64(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float64).contiguous()
+
+
+def require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on '{t.device}'.  pgmuvi_amd evaluates the GP marginal likelihood only with its HIP "
+            "kernels on an MI355X (move the model and data with .cuda()); there is no CPU fallback.")
+
+
+class Workspace:
+    """Owns a ``pgm_ws`` (device buffers sized for max_n / max_q / max_d / max_batch)."""
+
+    def __init__(self, device: torch.device, max_n: int, max_q: int, max_d: int, max_batch: int = 1):
+        lib = load()
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.key = (idx, max_n, max_q, max_d, max_batch)
+        handle = c_void_p()
+        _check(lib.pgm_workspace_create(byref(handle), idx, max_n, max_q, max_d, max_batch), "pgm_workspace_create")
+        self.handle = handle
+        self.max_n, self.max_q, self.max_d, self.max_batch = max_n, max_q, max_d, max_batch
+        self.bytes = int(lib.pgm_workspace_bytes(handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().pgm_workspace_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- profiling ---------------------------------------------------------
+    def profile(self, on: bool):
+        _check(load().pgm_profile_enable(self.handle, 1 if on else 0), "pgm_profile_enable")
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        lib = load()
+        n = lib.pgm_profile_phases()
+        ms = (c_double * n)()
+        cnt = (c_int64 * n)()
+        _check(lib.pgm_profile_read(self.handle, ms, cnt), "pgm_profile_read")
+        return {lib.pgm_profile_phase_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+_workspaces: Dict[tuple, Workspace] = {}
+
+
+def get_workspace(device, n: int, q: int, d: int, batch: int = 1) -> Workspace:
+    """Cached workspace large enough for (n, q, d, batch) on `device` (sizes round up
+    so that a fit loop with fixed shapes allocates once)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    np_ = (n + 127) // 128 * 128
+    key = (idx, np_, q, d, batch)
+    ws = _workspaces.get(key)
+    if ws is None:
+        for k in [k for k in _workspaces if k[0] == idx and k != key]:
+            _workspaces.pop(k).close()          # one live workspace per device: they are big
+        ws = Workspace(torch.device("cuda", idx), np_, q, d, batch)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces():
+    for k in list(_workspaces):
+        _workspaces.pop(k).close()
+
+
+def current_stream_ptr(device) -> c_void_p:
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def sm_kernel_dense(x1, x2, w, mu, v, noise=None, noise_scalar: float = 0.0, dim_order: int = 0) -> torch.Tensor:
+    """Dense K(x1, x2) (+ diag noise when x1 is x2) through pgm_sm_kernel_f64."""
+    require_gpu(x1, "sm_kernel_dense")
+    dev = x1.device
+    same = x2 is x1
+    x1d = _dev64(x1.reshape(x1.shape[0], -1), dev)
+    x2d = x1d if same else _dev64(x2.reshape(x2.shape[0], -1), dev)
+    n1, d = x1d.shape
+    n2 = x2d.shape[0]
+    q = w.numel()
+    wd, mud, vd = _dev64(w.reshape(q), dev), _dev64(mu.reshape(q, d), dev), _dev64(v.reshape(q, d), dev)
+    nz = None if noise is None else _dev64(noise.reshape(n1), dev)
+    K = torch.empty((n1, n2), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().pgm_sm_kernel_f64(_ptr(x1d), n1, _ptr(x2d), n2, d, _ptr(wd), _ptr(mud), _ptr(vd), q, _ptr(nz),
+                                      float(noise_scalar), int(dim_order), _ptr(K), n2, current_stream_ptr(dev))
+    _check(rc, "pgm_sm_kernel_f64")
+    return K
+
+
+def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitter=0.0, need_grad=True,
+                   workspace: Optional[Workspace] = None):
+    """One (or a batch of) MLL evaluation(s) through the C ABI.
+
+    Unbatched shapes: x (n,d) y (n) mean (n) noise (n)|None noise_scalar float|0-dim tensor, w (q) mu (q,d) v (q,d).
+    Batched: a leading batch dimension on everything (noise_scalar: (B,) tensor or None).
+    Returns dict(mll, g_w, g_mu, g_v, g_noise, g_mean, info) of device tensors (fp64); no host sync.
+    """
+    require_gpu(x, "mll_value_grad")
+    dev = x.device
+    batched = y.dim() == 2
+    B = y.shape[0] if batched else 1
+    n = y.shape[-1]
+    xd = _dev64(x.reshape(B, n, -1), dev)
+    d = xd.shape[-1]
+    q = w.shape[-1] if w.dim() > 0 else 1
+    yd = _dev64(y.reshape(B, n), dev)
+    md = _dev64(mean.expand(y.shape).reshape(B, n), dev)
+    nz = None if noise is None else _dev64(noise.expand(y.shape).reshape(B, n), dev)
+    wd = _dev64(w.reshape(B, q), dev)
+    mud = _dev64(mu.reshape(B, q, d), dev)
+    vd = _dev64(v.reshape(B, q, d), dev)
+    ws = workspace or get_workspace(dev, n, q, d, B)
+    out = dict(
+        mll=torch.empty(B, dtype=torch.float64, device=dev),
+        info=torch.zeros(B, dtype=torch.int32, device=dev),
+    )
+    if need_grad:
+        out.update(
+            g_w=torch.empty((B, q), dtype=torch.float64, device=dev),
+            g_mu=torch.empty((B, q, d), dtype=torch.float64, device=dev),
+            g_v=torch.empty((B, q, d), dtype=torch.float64, device=dev),
+            g_noise=torch.empty((B, n), dtype=torch.float64, device=dev),
+            g_mean=torch.empty((B, n), dtype=torch.float64, device=dev),
+        )
+    g = lambda k: _ptr(out.get(k))
+    lib = load()
+    with torch.cuda.device(dev):
+        st = current_stream_ptr(dev)
+        # always the batched entry point (B = 1 when unbatched): the scalar noise then
+        # travels as a device pointer and no host synchronisation is needed
+        ns = None
+        if noise_scalar is not None:
+            ns = _dev64(torch.as_tensor(noise_scalar, device=dev).expand(B).reshape(B), dev)
+        rc = lib.pgm_mll_value_grad_batched_f64(
+            ws.handle, B, _ptr(xd), _ptr(yd), _ptr(md), _ptr(nz), _ptr(ns), n, d, _ptr(wd), _ptr(mud), _ptr(vd), q,
+            int(dim_order), float(jitter), 1 if need_grad else 0,
+            g("mll"), g("g_w"), g("g_mu"), g("g_v"), g("g_noise"), g("g_mean"), g("info"), st)
+        _check(rc, "pgm_mll_value_grad_batched_f64")
+        out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
+    if not batched:
+        for k in ("mll", "info", "g_w", "g_mu", "g_v", "g_noise", "g_mean"):
+            if k in out:
+                out[k] = out[k][0]
+    out["workspace"] = ws
+    return out
+
+
+def probe_mfma_f64(device_index: int = 0) -> float:
+    val = c_double()
+    _check(load().pgm_probe_mfma_f64(device_index, byref(val)), "pgm_probe_mfma_f64")
+    return float(val.value)
+
+
+def predict(ws: Workspace, x_test: torch.Tensor, mean_test: torch.Tensor):
+    """Posterior mean and latent variance at ``x_test`` from the factor the last
+    ``mll_value_grad(need_grad=True)`` call left in ``ws`` (pgm_predict_f64)."""
+    require_gpu(x_test, "predict")
+    dev = x_test.device
+    xt = _dev64(x_test.reshape(x_test.shape[0], -1), dev)
+    m = xt.shape[0]
+    mt = _dev64(mean_test.expand(m).reshape(m), dev)
+    pm = torch.empty(m, dtype=torch.float64, device=dev)
+    pv = torch.empty(m, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().pgm_predict_f64(ws.handle, _ptr(xt), _ptr(mt), m, _ptr(pm), _ptr(pv), current_stream_ptr(dev))
+    _check(rc, "pgm_predict_f64")
+    return pm, pv

@@ -1,0 +1,159 @@
+// pgm_gemm.h -- the one dense contraction of the path, on CDNA4 fp64 MFMA.
+//
+//   acc[m][n] += sum_k A[k][m] * B[k][n]          ("TN": both operands k-major)
+//
+// Every GEMM-shaped step of the blocked factorisation is this product on 128-row
+// k-blocks of row-major storage (see DESIGN.md "Data layout"): factoring the UPPER
+// triangle (A = U^T U) makes the panel operands U[k][:] contiguous along the output
+// index, so global loads are coalesced 16-B/lane and the LDS image [k][m] is exactly
+// what v_mfma_f64_16x16x4_f64 wants (lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; D: col = l&15, row = (l>>4) + 4*reg).
+//
+// 256 threads = 4 wavefronts (64 lanes), one per SIMD; each wave owns a WM x WN
+// sub-tile as TM x TN MFMA tiles with the accumulators in registers.  k advances in
+// chunks of KB=16 rows, double-buffered in LDS with the next chunk's global loads in
+// flight behind the current chunk's MFMAs (one barrier per chunk).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int NB = 128;   // block size of the blocked algorithms (rows per k-block)
+constexpr int KB = 16;    // k rows staged per LDS chunk
+constexpr int NTHREADS = 256;
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int TM = WM / 16, TN = WN / 16;
+  static constexpr int WAVES_N = BN / WN;
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  // LDS row pitch (doubles) == 16 (mod 32): the two k rows a 32-lane group of
+  // ds_read_b64 touches land on disjoint halves of the 64 banks.
+  static constexpr int PA = BM + 16, PB = BN + 16;
+  static constexpr int STAGE = KB * (PA + PB);
+  static constexpr int LDS_DOUBLES = 2 * STAGE;
+  static constexpr int VA = KB * BM / 2 / NTHREADS;
+  static constexpr int VB = KB * BN / 2 / NTHREADS;
+  static_assert(VA >= 1 && VB >= 1, "tile too small for the 16-B staging loads");
+};
+
+struct WavePos {
+  int lane, wave, m0, n0;
+};
+
+template <class C>
+__device__ __forceinline__ WavePos wave_pos() {
+  WavePos p;
+  p.lane = threadIdx.x & 63;
+  p.wave = threadIdx.x >> 6;
+  p.m0 = (p.wave / C::WAVES_N) * C::WM;
+  p.n0 = (p.wave % C::WAVES_N) * C::WN;
+  return p;
+}
+// element (ti, tj, r) of a wave's accumulator sits at tile-local (row, col):
+template <class C>
+__device__ __forceinline__ int acc_row(const WavePos& p, int ti, int r) { return p.m0 + ti * 16 + (p.lane >> 4) + 4 * r; }
+template <class C>
+__device__ __forceinline__ int acc_col(const WavePos& p, int tj) { return p.n0 + tj * 16 + (p.lane & 15); }
+
+// ptrs(kb, pa, lda, pb, ldb): operand tile pointers of k-block kb: A tile is
+// NB x BM at pa (row pitch lda), B tile NB x BN at pb.
+template <class C, class PtrFn>
+__device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn&& ptrs,
+                                        v4d (&acc)[C::TM][C::TN]) {
+  const int t = threadIdx.x;
+  const WavePos wp = wave_pos<C>();
+  const int nchunks = nkb * (NB / KB);
+  v2d ra[C::VA], rb[C::VB];
+
+  auto gload = [&](int c) {
+    const int kb = c / (NB / KB), kr = (c % (NB / KB)) * KB;
+    const double* pa; const double* pb; int64_t lda, ldb;
+    ptrs(kb, pa, lda, pb, ldb);
+#pragma unroll
+    for (int s = 0; s < C::VA; ++s) {
+      const int e = t + NTHREADS * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
+      ra[s] = *reinterpret_cast<const v2d*>(pa + (int64_t)(kr + row) * lda + 2 * c2);
+    }
+#pragma unroll
+    for (int s = 0; s < C::VB; ++s) {
+      const int e = t + NTHREADS * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
+      rb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
+    }
+  };
+  auto sstore = [&](int buf) {
+    double* As = lds + buf * C::STAGE;
+    double* Bs = As + KB * C::PA;
+#pragma unroll
+    for (int s = 0; s < C::VA; ++s) {
+      const int e = t + NTHREADS * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
+      *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = ra[s];
+    }
+#pragma unroll
+    for (int s = 0; s < C::VB; ++s) {
+      const int e = t + NTHREADS * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
+      *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = rb[s];
+    }
+  };
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = (c + 1 < nchunks);
+    if (more) gload(c + 1);
+    const double* As = lds + (c & 1) * C::STAGE;
+    const double* Bs = As + KB * C::PA;
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+      const int krow = kk * 4 + (wp.lane >> 4);
+      double a[C::TM], b[C::TN];
+#pragma unroll
+      for (int ti = 0; ti < C::TM; ++ti) a[ti] = As[krow * C::PA + wp.m0 + ti * 16 + (wp.lane & 15)];
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj) b[tj] = Bs[krow * C::PB + wp.n0 + tj * 16 + (wp.lane & 15)];
+#pragma unroll
+      for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < C::TN; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+    if (more) sstore((c + 1) & 1);
+    __syncthreads();
+  }
+}
+
+// acc = -C (so that the accumulated result is -(C - A^T B)); C tile at c, pitch ldc
+template <class C>
+__device__ __forceinline__ void acc_load_neg(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) {
+  const WavePos wp = wave_pos<C>();
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[ti][tj][r] = -c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)];
+}
+template <class C>
+__device__ __forceinline__ void acc_zero(v4d (&acc)[C::TM][C::TN]) {
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj] = v4d{0.0, 0.0, 0.0, 0.0};
+}
+// C = sign * acc
+template <class C>
+__device__ __forceinline__ void acc_store(double* __restrict__ c, int64_t ldc, const v4d (&acc)[C::TM][C::TN], double sign) {
+  const WavePos wp = wave_pos<C>();
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)] = sign * acc[ti][tj][r];
+}

@@ -1,0 +1,56 @@
+// pgm_internal.h -- workspace layout shared by the kernels and the host driver.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "pgm_gemm.h"
+
+constexpr int PGM_MAX_QD = 16;      // Q*d the LDS staging is sized for
+constexpr int PGM_MAX_D = 2;
+
+// Device view of one call (passed by value to every kernel).  All problems of a
+// batch share sizes; buffer b of a batch sits at base + b * stride.
+struct PgmDev {
+  int n, np, nb, q, d, qd, dim_order, need_grad, batch;
+  int nslot, ntiles, pre_slots;
+  int64_t ld;                                   // == np
+  int64_t sA, sDinv, sPre, sVec, sPart, sLogdet;
+  double* A;          // [batch][np*np]  upper blocks: K+noise -> U ; strictly lower blocks: V = U^-T
+  double* Dinv;       // [batch][nb][2][NB*NB]  0: Uinv_kk ([p][m])   1: Uinv_kk^T = V_kk ([k][n])
+  double* pre;        // [batch][3*qd + d][np]  cos, sin, x*v per (q,d); raw x per d
+  double* r;          // [batch][np]  residual y - mean, consumed by the forward substitution
+  double* z;          // [batch][np]  U^-T r
+  double* alpha;      // [batch][np]  A^-1 r
+  double* logdet;     // [batch][nb]
+  double* partials;   // [batch][ntiles][nslot]
+  double* hyp;        // [batch][q + 2*q*d] copy of (w, mu, v) kept for prediction
+  int* info;          // [batch]
+  double jitter, noise_scalar;
+  const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
+  double *mll, *g_w, *g_mu, *g_v, *g_noise, *g_mean;
+  int* info_out;
+};
+
+enum PgmPhase { PH_PRE = 0, PH_BUILD, PH_DIAG, PH_TRSM, PH_UPDATE, PH_LAUUM, PH_FINAL, PH_COUNT };
+
+struct pgm_ws {
+  int device;
+  int64_t max_n, max_np;
+  int max_q, max_d, max_batch, max_nb;
+  size_t bytes;
+  double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp;
+  int* info;
+  // state of the last need_grad evaluation (for pgm_predict_f64)
+  PgmDev last;
+  bool last_valid;
+  double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
+  size_t pred_bytes;
+  // profiling
+  bool prof_on;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_phase;      // phase of event pair i (events 2i, 2i+1)
+  size_t ev_used;
+  hipStream_t prof_stream;
+  double prof_ms[PH_COUNT];
+  int64_t prof_launches[PH_COUNT];
+};

@@ -1,0 +1,700 @@
+// pgm_kernels.hip -- device kernels of the exact-GP hot path (gfx950 only).
+//
+// One evaluation = SM kernel build -> blocked factorisation sweep (Cholesky + the
+// inverse factor in the same sweep) -> A^-1 tiles with the gradient contraction
+// fused into their epilogue -> a tiny finalise.  See DESIGN.md for the algorithm
+// and data layout; reference call sites are cited in include/pgmuvi_hip.h.
+#include "pgm_internal.h"
+
+namespace {
+
+constexpr double PI = 3.14159265358979323846;
+constexpr double TWO_PI_SQ = 2.0 * PI * PI;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// idx -> (i <= j) of the column-major enumeration of an upper triangle
+__device__ __forceinline__ void tri_decode(int idx, int& i, int& j) {
+  int jj = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+  while ((jj + 1) * (jj + 2) / 2 <= idx) ++jj;
+  while (jj * (jj + 1) / 2 > idx) --jj;
+  j = jj;
+  i = idx - jj * (jj + 1) / 2;
+}
+
+// ---------------------------------------------------------------------------
+// Per-point factors.  GPyTorch evaluates cos(2 pi (x_i mu - x_j mu)); the angle
+// difference is expanded (cos a cos b + sin a sin b) so the N^2 pass needs no
+// trigonometry, only the N*Q*d sincospi here.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_precompute(PgmDev P) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.info[b] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < P.q + 2 * P.qd) {
+    const int s = threadIdx.x;
+    double val;
+    if (s < P.q) val = P.w[(int64_t)b * P.q + s];
+    else if (s < P.q + P.qd) val = P.mu[(int64_t)b * P.qd + (s - P.q)];
+    else val = P.v[(int64_t)b * P.qd + (s - P.q - P.qd)];
+    P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + s] = val;
+  }
+  if (i >= P.np) return;
+  double* pre = P.pre + b * P.sPre;
+  const bool valid = i < P.n;
+  for (int dd = 0; dd < P.d; ++dd) {
+    const double xi = valid ? P.x[((int64_t)b * P.n + i) * P.d + dd] : 0.0;
+    pre[(int64_t)(3 * P.qd + dd) * P.np + i] = xi;
+    for (int q = 0; q < P.q; ++q) {
+      const int qd = q * P.d + dd;
+      const double mu = P.mu[(int64_t)b * P.qd + qd], v = P.v[(int64_t)b * P.qd + qd];
+      double s, c;
+      sincospi(2.0 * (xi * mu), &s, &c);
+      pre[(int64_t)(qd * 3 + 0) * P.np + i] = c;
+      pre[(int64_t)(qd * 3 + 1) * P.np + i] = s;
+      pre[(int64_t)(qd * 3 + 2) * P.np + i] = xi * v;
+    }
+  }
+  const int64_t vi = (int64_t)b * P.sVec + i;
+  P.r[vi] = valid ? (P.y[(int64_t)b * P.n + i] - P.mean[(int64_t)b * P.n + i]) : 0.0;
+}
+
+// stage the per-point factor slices of block row `ib` and block column `jb` in LDS
+__device__ __forceinline__ void stage_factors(const PgmDev& P, const double* pre, int ib, int jb,
+                                              double* rowd, double* cold) {
+  const int total = P.pre_slots * NB;
+  for (int e = threadIdx.x; e < total; e += NTHREADS) {
+    const int slot = e / NB, m = e % NB;
+    rowd[e] = pre[(int64_t)slot * P.np + ib * NB + m];
+    cold[e] = pre[(int64_t)slot * P.np + jb * NB + m];
+  }
+}
+
+// k(x_m, x_n) from staged factors (m, n tile-local)
+template <int D, int ORDER>
+__device__ __forceinline__ double sm_pair(const double* rowd, const double* cold, const double* wl,
+                                          int Q, int m, int n) {
+  double S[D];
+#pragma unroll
+  for (int dd = 0; dd < D; ++dd) S[dd] = 0.0;
+  double K1 = 0.0;
+  for (int q = 0; q < Q; ++q) {
+    double prod = 1.0;
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      const int qd = q * D + dd;
+      const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
+      const double e = exp(-TWO_PI_SQ * ds * ds);
+      const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
+                        rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
+      if (ORDER == 0) S[dd] += wl[q] * e * cc; else prod *= e * cc;
+    }
+    if (ORDER != 0) K1 += wl[q] * prod;
+  }
+  if (ORDER != 0) return K1;
+  double K = 1.0;
+#pragma unroll
+  for (int dd = 0; dd < D; ++dd) K *= S[dd];
+  return K;
+}
+
+// ---------------------------------------------------------------------------
+// A = K + diag(noise + noise_scalar + jitter), upper block triangle only, padded
+// with the identity.  One workgroup per 128x128 tile; a wave stores one full row
+// (1 KiB) per instruction.
+// ---------------------------------------------------------------------------
+template <int D, int ORDER>
+__global__ __launch_bounds__(256) void k_build(PgmDev P) {
+  const int b = blockIdx.z;
+  int ib, jb;
+  tri_decode(blockIdx.x, ib, jb);
+  __shared__ double sm[2 * (3 * PGM_MAX_QD + PGM_MAX_D) * NB + PGM_MAX_QD];
+  double* rowd = sm;
+  double* cold = sm + P.pre_slots * NB;
+  double* wl = cold + P.pre_slots * NB;
+  const double* pre = P.pre + b * P.sPre;
+  stage_factors(P, pre, ib, jb, rowd, cold);
+  if (threadIdx.x < P.q) wl[threadIdx.x] = P.w[(int64_t)b * P.q + threadIdx.x];
+  __syncthreads();
+  double* A = P.A + b * P.sA;
+  const double nsc = P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[b] : 0.0) + P.jitter;
+  const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    const int m = rg + 4 * rr;
+    const int gi = ib * NB + m;
+    v2d out;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int nloc = c2 + u, gj = jb * NB + nloc;
+      double val;
+      if (gi < P.n && gj < P.n) {
+        val = sm_pair<D, ORDER>(rowd, cold, wl, P.q, m, nloc);
+        if (gi == gj) val += nsc + (P.noise ? P.noise[(int64_t)b * P.n + gi] : 0.0);
+      } else {
+        val = (gi == gj) ? 1.0 : 0.0;
+      }
+      out[u] = val;
+    }
+    *reinterpret_cast<v2d*>(A + (int64_t)gi * P.ld + jb * NB + c2) = out;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Diagonal block k:  U_kk = chol_upper(A_kk), Uinv_kk and its transpose, the
+// block's share of log det, z_k = Uinv_kk^T r_k and alpha_k = Uinv_kk z_k.
+// Register-resident elimination: thread (ti,tj) of a 16x16 grid owns the 8x8
+// elements (ti+16a, tj+16b) of A_kk and of the evolving inverse factor; only the
+// pivot row travels through LDS (double-buffered, one barrier per column).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void k_diag(PgmDev P, int k) {
+  const int b = blockIdx.z;
+  if (P.info[b] != 0) return;
+  double* A = P.A + b * P.sA;
+  double* Akk = A + (int64_t)k * NB * P.ld + k * NB;
+  constexpr int VP = NB + 1;
+  __shared__ double Vs[NB * VP];
+  __shared__ double rowT[2][NB], rowR[2][NB], dbuf[NB], zs[NB], rs[NB], red[4];
+  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
+  double Tm[8][8], Rm[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int i = ti + 16 * a, j = tj + 16 * c;
+      Tm[a][c] = (c >= a) ? Akk[(int64_t)i * P.ld + j] : 0.0;
+      Rm[a][c] = (i == j) ? 1.0 : 0.0;
+    }
+  if (t < NB) rs[t] = P.r[b * P.sVec + k * NB + t];
+
+  for (int p = 0; p < NB; ++p) {
+    const int pa = p >> 4, pt = p & 15, buf = p & 1;
+    if (ti == pt) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (a == pa) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            rowT[buf][tj + 16 * c] = Tm[a][c];
+            rowR[buf][tj + 16 * c] = Rm[a][c];
+          }
+        }
+    }
+    __syncthreads();
+    double dpiv = rowT[buf][p];
+    if (!(dpiv > 0.0)) {
+      if (t == 0 && P.info[b] == 0) P.info[b] = k * NB + p + 1;
+      dpiv = 1.0;
+    }
+    if (t == 0) dbuf[p] = dpiv;
+    const double rinv = 1.0 / dpiv;
+    double lj[8], rj[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      lj[c] = rowT[buf][tj + 16 * c];
+      rj[c] = rowR[buf][tj + 16 * c];
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (a >= pa) {
+        const int i = ti + 16 * a;
+        const double li = (i > p) ? rowT[buf][i] * rinv : 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (c >= a) Tm[a][c] -= li * lj[c];
+          if (c <= pa) Rm[a][c] -= li * rj[c];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // scale rows by d_i^-1/2; U to the matrix, V = Uinv^T to LDS
+  double* Dk = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int i = ti + 16 * a;
+    const double sc = 1.0 / sqrt(dbuf[i]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int j = tj + 16 * c;
+      Akk[(int64_t)i * P.ld + j] = (j >= i) ? Tm[a][c] * sc : 0.0;
+      Vs[i * VP + j] = (j <= i) ? Rm[a][c] * sc : 0.0;
+    }
+  }
+  __syncthreads();
+  {
+    const int cidx = t & 127, r0 = t >> 7;
+    for (int s = 0; s < NB / 2; ++s) {
+      const int rrow = r0 + 2 * s;
+      Dk[NB * NB + rrow * NB + cidx] = Vs[rrow * VP + cidx];   // Uinv^T = V_kk, [k][n]
+      Dk[rrow * NB + cidx] = Vs[cidx * VP + rrow];             // Uinv [p][m] = V[m][p]
+    }
+  }
+  if (t < NB) {
+    double acc = 0.0;
+    for (int j = 0; j <= t; ++j) acc += Vs[t * VP + j] * rs[j];
+    zs[t] = acc;
+    P.z[b * P.sVec + k * NB + t] = acc;
+  }
+  double lg = (t < NB) ? log(dbuf[t]) : 0.0;
+  lg = wave_sum(lg);
+  if ((t & 63) == 0) red[t >> 6] = lg;
+  __syncthreads();
+  if (t < NB) {
+    double acc = 0.0;
+    for (int i = t; i < NB; ++i) acc += Vs[i * VP + t] * zs[i];
+    P.alpha[b * P.sVec + k * NB + t] = acc;
+  }
+  if (t == 0) P.logdet[b * P.sLogdet + k] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------
+// Block row k after its diagonal block:  C <- Uinv_kk^T C for every other block of
+// the row (U_kj for j > k, V_kj for j < k), 128 x 32 column slabs, in place.
+// Epilogue: the forward substitution rides along,  r_j -= U_kj^T z_k  (j > k), and
+// so does alpha,  alpha_j += V_kj^T z_k  (j < k).
+// ---------------------------------------------------------------------------
+using CfgTrsm = TileCfg<128, 32, 32, 32>;
+__global__ __launch_bounds__(256) void k_trsm(PgmDev P, int k) {
+  using C = CfgTrsm;
+  const int b = blockIdx.z;
+  if (P.info[b] != 0) return;
+  const int slab = blockIdx.x & 3;
+  int jb = blockIdx.x >> 2;
+  if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
+  double* A = P.A + b * P.sA;
+  double* Cb = A + (int64_t)k * NB * P.ld + jb * NB + slab * C::BN;
+  const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  __shared__ double zs[NB];
+  __shared__ double red[4][C::BN];
+  if (threadIdx.x < NB) zs[threadIdx.x] = P.z[b * P.sVec + k * NB + threadIdx.x];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  const int64_t ld = P.ld;
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = Uinv; lda = NB; pb = Cb; ldb = ld;
+  }, acc);
+  acc_store<C>(Cb, ld, acc, 1.0);
+  const WavePos wp = wave_pos<C>();
+#pragma unroll
+  for (int tj = 0; tj < C::TN; ++tj) {
+    double s = 0.0;
+#pragma unroll
+    for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += acc[ti][tj][r] * zs[acc_row<C>(wp, ti, r)];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (wp.lane < 16) red[wp.wave][tj * 16 + wp.lane] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < C::BN) {
+    const int c = threadIdx.x;
+    const double tot = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    const int64_t g = b * P.sVec + jb * NB + slab * C::BN + c;
+    if (jb > k) P.r[g] -= tot; else P.alpha[g] += tot;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Step k trailing update (the dominant kernel):
+//   A_ij -= U_ki^T U_kj   k < i <= j           (Cholesky trailing update)
+//   R_ij -= U_ki^T V_kj   i > k >= j           (inverse factor, same sweep)
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256) void k_update(PgmDev P, int k) {
+  const int b = blockIdx.z;
+  if (P.info[b] != 0) return;
+  constexpr int SUB = NB / C::BM;
+  static_assert(C::BM == C::BN, "square tiles");
+  const int sub = blockIdx.x % (SUB * SUB), tile = blockIdx.x / (SUB * SUB);
+  const int si = sub / SUB, sj = sub % SUB;
+  const int nrem = P.nb - 1 - k, nsyrk = nrem * (nrem + 1) / 2;
+  int i, j;
+  if (tile < nsyrk) {
+    tri_decode(tile, i, j);
+    i += k + 1; j += k + 1;
+  } else {
+    const int t2 = tile - nsyrk;
+    i = k + 1 + t2 / (k + 1);
+    j = t2 % (k + 1);
+  }
+  double* A = P.A + b * P.sA;
+  const int64_t ld = P.ld;
+  const double* pa0 = A + (int64_t)k * NB * ld + i * NB + si * C::BM;
+  const double* pb0;
+  int64_t ldb0;
+  if (j == k) { pb0 = P.Dinv + b * P.sDinv + ((int64_t)k * 2 + 1) * NB * NB + sj * C::BN; ldb0 = NB; }
+  else { pb0 = A + (int64_t)k * NB * ld + j * NB + sj * C::BN; ldb0 = ld; }
+  double* Cp = A + ((int64_t)i * NB + si * C::BM) * ld + j * NB + sj * C::BN;
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  if (j == k) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
+  }, acc);
+  acc_store<C>(Cp, ld, acc, -1.0);
+}
+
+// ---------------------------------------------------------------------------
+// A^-1 tile (i <= j) = sum_{p >= j} V_pi^T V_pj, never written to memory: the
+// epilogue forms G = alpha alpha^T - A^-1 and contracts it with dK/d(w, mu, v)
+// recomputed from the per-point factors, leaving one partial sum per hyper-
+// parameter and tile (summed in fixed order by k_finalize: bitwise reproducible).
+// ---------------------------------------------------------------------------
+using CfgBig = TileCfg<128, 128, 64, 64>;
+using CfgSmall = TileCfg<64, 64, 32, 32>;
+constexpr int LAUUM_LDS_DOUBLES = 2 * (3 * PGM_MAX_QD + PGM_MAX_D) * NB + 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);
+static_assert(LAUUM_LDS_DOUBLES >= CfgBig::LDS_DOUBLES, "epilogue scratch must cover the GEMM stages");
+
+template <int D, int ORDER>
+__global__ __launch_bounds__(256, 1) void k_lauum_grad(PgmDev P) {
+  using C = CfgBig;
+  const int b = blockIdx.z;
+  if (P.info[b] != 0) return;
+  int i, j;
+  tri_decode(blockIdx.x, i, j);
+  double* A = P.A + b * P.sA;
+  const double* Dv = P.Dinv + b * P.sDinv;
+  const int64_t ld = P.ld;
+  __shared__ __attribute__((aligned(16))) double lds[LAUUM_LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  gemm_tn<C>(lds, P.nb - j, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    const int p = j + kb;
+    if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB; lda = ld; }
+    else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB; lda = NB; }
+    if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB; ldb = ld; }
+    else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB; ldb = NB; }
+  }, acc);
+
+  // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
+  const int Q = P.q;
+  double* rowd = lds;
+  double* cold = rowd + P.pre_slots * NB;
+  double* arow = cold + P.pre_slots * NB;
+  double* acol = arow + NB;
+  double* wl = acol + NB;
+  double* wpart = wl + PGM_MAX_QD;            // [4][nslot]
+  stage_factors(P, P.pre + b * P.sPre, i, j, rowd, cold);
+  if (threadIdx.x < NB) {
+    arow[threadIdx.x] = P.alpha[b * P.sVec + i * NB + threadIdx.x];
+    acol[threadIdx.x] = P.alpha[b * P.sVec + j * NB + threadIdx.x];
+  }
+  if (threadIdx.x < Q) wl[threadIdx.x] = P.w[(int64_t)b * P.q + threadIdx.x];
+  for (int e = threadIdx.x; e < 4 * P.nslot; e += NTHREADS) wpart[e] = 0.0;
+  __syncthreads();
+
+  const WavePos wp = wave_pos<C>();
+  const double sym = (i == j) ? 1.0 : 2.0;
+  const double half_n = 0.5 / (double)P.n;
+  double* mypart = wpart + wp.wave * P.nslot;
+  const double* rowx = rowd + 3 * P.qd * NB;
+  const double* colx = cold + 3 * P.qd * NB;
+  double gns = 0.0;
+#pragma unroll 1
+  for (int ti = 0; ti < C::TM; ++ti) {
+    double Gw[C::TN][4];
+    double Sd[D][C::TN][4];
+    // runtime ti would index acc dynamically: select statically
+    v4d accrow[C::TN];
+#pragma unroll
+    for (int tt = 0; tt < C::TM; ++tt)
+      if (tt == ti) {
+#pragma unroll
+        for (int tj = 0; tj < C::TN; ++tj) accrow[tj] = acc[tt][tj];
+      }
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+        const int gi = i * NB + m, gj = j * NB + n;
+        const bool valid = (gi < P.n) && (gj < P.n);
+        const double g = valid ? (arow[m] * acol[n] - accrow[tj][r]) : 0.0;
+        Gw[tj][r] = sym * g;
+        if (i == j && m == n && valid) {
+          gns += g;
+          if (P.g_noise) P.g_noise[(int64_t)b * P.n + gi] = half_n * g;
+        }
+      }
+    if (D == 2 && ORDER == 0) {
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+        for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Sd[dd][tj][r] = 0.0;
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          const int qd = q * D + dd;
+#pragma unroll
+          for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+              const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
+              const double e = exp(-TWO_PI_SQ * ds * ds);
+              const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
+                                rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
+              Sd[dd][tj][r] += wl[q] * e * cc;
+            }
+        }
+      }
+    }
+    for (int q = 0; q < Q; ++q) {
+      double gw = 0.0, gmu[D], gv[D];
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) { gmu[dd] = 0.0; gv[dd] = 0.0; }
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+          double E[D], CC[D], SN[D], TAU[D];
+#pragma unroll
+          for (int dd = 0; dd < D; ++dd) {
+            const int qd = q * D + dd;
+            const double rc = rowd[(qd * 3 + 0) * NB + m], rsn = rowd[(qd * 3 + 1) * NB + m];
+            const double cc_ = cold[(qd * 3 + 0) * NB + n], cs_ = cold[(qd * 3 + 1) * NB + n];
+            const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
+            E[dd] = exp(-TWO_PI_SQ * ds * ds);
+            CC[dd] = rc * cc_ + rsn * cs_;
+            SN[dd] = rsn * cc_ - rc * cs_;
+            TAU[dd] = rowx[dd * NB + m] - colx[dd * NB + n];
+          }
+          const double G = Gw[tj][r];
+          if (D == 1) {
+            const double GE = G * E[0];
+            gw += GE * CC[0];
+            gmu[0] += GE * SN[0] * TAU[0];
+            gv[0] += GE * CC[0] * TAU[0] * TAU[0];
+          } else {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+              const int o = (D == 2) ? 1 - dd : 0;
+              const double oth = (ORDER == 0) ? Sd[o][tj][r] : E[o] * CC[o];
+              const double GE = G * oth * E[dd];
+              if (ORDER == 0) gw += GE * CC[dd];
+              gmu[dd] += GE * SN[dd] * TAU[dd];
+              gv[dd] += GE * CC[dd] * TAU[dd] * TAU[dd];
+            }
+            if (ORDER != 0) gw += G * E[0] * CC[0] * E[1 % D] * CC[1 % D];
+          }
+        }
+      gw = wave_sum(gw);
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) { gmu[dd] = wave_sum(gmu[dd]); gv[dd] = wave_sum(gv[dd]); }
+      if (wp.lane == 0) {
+        mypart[q] += gw;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+          mypart[Q + q * D + dd] += gmu[dd];
+          mypart[Q + Q * D + q * D + dd] += gv[dd];
+        }
+      }
+    }
+  }
+  gns = wave_sum(gns);
+  if (wp.lane == 0) mypart[P.nslot - 1] += gns;
+  __syncthreads();
+  double* part = P.partials + b * P.sPart + (int64_t)blockIdx.x * P.nslot;
+  for (int s = threadIdx.x; s < P.nslot; s += NTHREADS)
+    part[s] = wpart[s] + wpart[P.nslot + s] + wpart[2 * P.nslot + s] + wpart[3 * P.nslot + s];
+}
+
+// ---------------------------------------------------------------------------
+// mll = -(||z||^2 + log det A + n log 2 pi) / 2n ;  gradients from the partials.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(PgmDev P) {
+  const int b = blockIdx.z, t = threadIdx.x;
+  __shared__ double red[4];
+  const int bad = P.info[b];
+  double s = 0.0;
+  for (int i = t; i < P.np; i += NTHREADS) { const double zi = P.z[b * P.sVec + i]; s += zi * zi; }
+  for (int kk = t; kk < P.nb; kk += NTHREADS) s += P.logdet[b * P.sLogdet + kk];
+  s = wave_sum(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) {
+    const double tot = red[0] + red[1] + red[2] + red[3];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    P.mll[b] = bad ? nan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
+    if (P.info_out) P.info_out[b] = bad;
+  }
+  if (!P.need_grad || bad) return;
+  const double half_n = 0.5 / (double)P.n;
+  const int Q = P.q, QD = P.qd;
+  const int wave = t >> 6, lane = t & 63;
+  for (int sidx = wave; sidx < P.nslot; sidx += NTHREADS / 64) {
+    double acc = 0.0;
+    const double* part = P.partials + b * P.sPart + sidx;
+    for (int tile = lane; tile < P.ntiles; tile += 64) acc += part[(int64_t)tile * P.nslot];
+    acc = wave_sum(acc);                       // fixed summation order: reproducible
+    if (lane != 0) continue;
+    if (sidx < Q) {
+      if (P.g_w) P.g_w[(int64_t)b * Q + sidx] = half_n * acc;
+    } else if (sidx < Q + QD) {
+      const int qd = sidx - Q, q = qd / P.d;
+      if (P.g_mu) P.g_mu[(int64_t)b * QD + qd] = half_n * (-2.0 * PI) * P.w[(int64_t)b * Q + q] * acc;
+    } else if (sidx < Q + 2 * QD) {
+      const int qd = sidx - Q - QD, q = qd / P.d;
+      if (P.g_v) P.g_v[(int64_t)b * QD + qd] = half_n * (-2.0 * TWO_PI_SQ) * P.v[(int64_t)b * QD + qd] * P.w[(int64_t)b * Q + q] * acc;
+    }
+    // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
+    // caller sums g_noise instead, so nothing to do here.
+  }
+  if (P.g_mean)
+    for (int i = t; i < P.n; i += NTHREADS) P.g_mean[(int64_t)b * P.n + i] = P.alpha[b * P.sVec + i] / (double)P.n;
+}
+
+// ---------------------------------------------------------------------------
+// Generic dense K(x1, x2) for to_dense() / cross-covariances (not on the MLL path).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sm_dense(const double* x1, int64_t n1, const double* x2, int64_t n2, int d,
+                                                  const double* w, const double* mu, const double* v, int q,
+                                                  const double* noise, double noise_scalar, int dim_order,
+                                                  double* K, int64_t ldk) {
+  const int64_t j = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= n1 || j >= n2) return;
+  double S[PGM_MAX_D] = {0.0, 0.0};
+  double K1 = 0.0;
+  for (int qq = 0; qq < q; ++qq) {
+    double prod = 1.0;
+    for (int dd = 0; dd < d; ++dd) {
+      const double a = x1[i * d + dd], c = x2[j * d + dd];
+      const double m = mu[qq * d + dd], s = v[qq * d + dd];
+      const double ds = a * s - c * s;
+      const double e = exp(-TWO_PI_SQ * ds * ds) * cospi(2.0 * (a * m - c * m));
+      if (dim_order == 0) S[dd] += w[qq] * e; else prod *= e;
+    }
+    if (dim_order != 0) K1 += w[qq] * prod;
+  }
+  double val = K1;
+  if (dim_order == 0) { val = 1.0; for (int dd = 0; dd < d; ++dd) val *= S[dd]; }
+  if (i == j && x1 == x2) val += noise_scalar + (noise ? noise[i] : 0.0);
+  K[i * ldk + j] = val;
+}
+
+// ---------------------------------------------------------------------------
+// Posterior prediction.  Ks[p][m] = k(x_p, x*_m) is
+// built tile-wise, then B = U^-T Ks by the same block forward substitution as the
+// factorisation sweep (row solve + trailing update on the right-hand sides), and
+//   mean*_m = m*_m + sum_p B[p][m] z_p ,   var*_m = k(x*,x*) - sum_p B[p][m]^2 .
+// ---------------------------------------------------------------------------
+template <int D, int ORDER>
+__global__ __launch_bounds__(256) void k_pred_cross(PgmDev P, const double* __restrict__ xt, int64_t M, int64_t Mp,
+                                                    double* __restrict__ Ks) {
+  const int jb = blockIdx.x, ib = blockIdx.y;
+  __shared__ double sm[2 * (3 * PGM_MAX_QD + PGM_MAX_D) * NB + PGM_MAX_QD];
+  double* rowd = sm;
+  double* cold = sm + P.pre_slots * NB;
+  double* wl = cold + P.pre_slots * NB;
+  const double* pre = P.pre;
+  const double* hyp = P.hyp;
+  for (int e = threadIdx.x; e < P.pre_slots * NB; e += NTHREADS) {
+    const int slot = e / NB, m = e % NB;
+    rowd[e] = pre[(int64_t)slot * P.np + ib * NB + m];
+  }
+  for (int e = threadIdx.x; e < P.qd * NB; e += NTHREADS) {
+    const int qd = e / NB, c = e % NB, dd = qd % P.d;
+    const int64_t gj = (int64_t)jb * NB + c;
+    const double xj = (gj < M) ? xt[gj * P.d + dd] : 0.0;
+    double s, co;
+    sincospi(2.0 * (xj * hyp[P.q + qd]), &s, &co);
+    cold[(qd * 3 + 0) * NB + c] = co;
+    cold[(qd * 3 + 1) * NB + c] = s;
+    cold[(qd * 3 + 2) * NB + c] = xj * hyp[P.q + P.qd + qd];
+  }
+  if (threadIdx.x < P.q) wl[threadIdx.x] = hyp[threadIdx.x];
+  __syncthreads();
+  const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    const int m = rg + 4 * rr;
+    const int gi = ib * NB + m;
+    v2d out;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t gj = (int64_t)jb * NB + c2 + u;
+      out[u] = (gi < P.n && gj < M) ? sm_pair<D, ORDER>(rowd, cold, wl, P.q, m, c2 + u) : 0.0;
+    }
+    *reinterpret_cast<v2d*>(Ks + (int64_t)gi * Mp + (int64_t)jb * NB + c2) = out;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pred_trsm(PgmDev P, int k, double* Ks, int64_t Mp) {
+  using C = CfgTrsm;
+  double* Cb = Ks + (int64_t)k * NB * Mp + (int64_t)blockIdx.x * C::BN;
+  const double* Uinv = P.Dinv + (int64_t)k * 2 * NB * NB;
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = Uinv; lda = NB; pb = Cb; ldb = Mp;
+  }, acc);
+  acc_store<C>(Cb, Mp, acc, 1.0);
+}
+
+__global__ __launch_bounds__(256) void k_pred_update(PgmDev P, int k, double* Ks, int64_t Mp) {
+  using C = CfgBig;
+  const int i = k + 1 + blockIdx.y;
+  const double* pa0 = P.A + (int64_t)k * NB * P.ld + i * NB;
+  const double* pb0 = Ks + (int64_t)k * NB * Mp + (int64_t)blockIdx.x * NB;
+  double* Cp = Ks + (int64_t)i * NB * Mp + (int64_t)blockIdx.x * NB;
+  const int64_t ld = P.ld;
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_load_neg<C>(Cp, Mp, acc);
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = pa0; lda = ld; pb = pb0; ldb = Mp;
+  }, acc);
+  acc_store<C>(Cp, Mp, acc, -1.0);
+}
+
+__global__ __launch_bounds__(256) void k_pred_reduce(PgmDev P, const double* __restrict__ Ks, int64_t M, int64_t Mp,
+                                                     const double* __restrict__ mean_test, double* __restrict__ mean_out,
+                                                     double* __restrict__ var_out) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int row = 0; row < P.np; ++row) {
+    const double bv = Ks[(int64_t)row * Mp + m];
+    s1 += bv * P.z[row];
+    s2 += bv * bv;
+  }
+  double wsum = 0.0;
+  for (int q = 0; q < P.q; ++q) wsum += P.hyp[q];
+  double kss = wsum;
+  if (P.dim_order == 0) for (int dd = 1; dd < P.d; ++dd) kss *= wsum;
+  if (mean_out) mean_out[m] = (mean_test ? mean_test[m] : 0.0) + s1;
+  if (var_out) var_out[m] = kss - s2;
+}
+
+// back-to-back fp64 MFMA issue probe
+__global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
+  v4d acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = v4d{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[u], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+}  // namespace
+
+// ===========================================================================
+// host side
+// ===========================================================================
+#include "pgm_host.inc"

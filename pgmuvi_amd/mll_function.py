@@ -1,0 +1,88 @@
+"""The single autograd node the whole hot path funnels into.
+
+``mll(output, y)`` of the reference (``/root/reference/pgmuvi/trainers.py:180``)
+ends here: one call of ``pgm_mll_value_grad*_f64`` computes the value and, when any
+input requires grad, every gradient in the same pass (rows A1+A3+A4+A5 of SURVEY.md
+section 8a); ``loss.backward()`` (``trainers.py:181``) then only scales the stored
+gradients.  Constraint transforms and the mean module stay in torch autograd (A2/A7).
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from . import _hip
+from .gpytorch import settings
+from .gpytorch.utils.errors import NanError, NotPSDError, NumericalWarning
+
+
+def _evaluate(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, need_grad):
+    """Runs the HIP evaluation with GPyTorch's psd_safe_cholesky retry policy:
+    jitter 0 first, then cholesky_jitter * 10**i for i < cholesky_max_tries."""
+    out = _hip.mll_value_grad(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, 0.0, need_grad)
+    if settings.check_cholesky_info.off():
+        return out, 0.0
+    info = out["info"]
+    if not bool((info != 0).any()):
+        return out, 0.0
+    if bool(torch.isnan(y).any()) or bool(torch.isnan(w).any()):
+        raise NanError("cholesky: NaN in the inputs of the marginal log likelihood.")
+    base = settings.cholesky_jitter.value(torch.float64)
+    jitter = 0.0
+    for i in range(settings.cholesky_max_tries.value()):
+        jitter = base * (10 ** i)
+        warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
+        out = _hip.mll_value_grad(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, jitter, need_grad)
+        if not bool((out["info"] != 0).any()):
+            return out, jitter
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
+
+
+class SMExactMLLFunction(torch.autograd.Function):
+    """mll per datum = log N(y | mean, K_SM(x,x) + diag(noise_vec) + noise_scalar I) / N.
+
+    Batched when ``y`` has a leading batch dimension (all problems the same N)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradients with respect to the inputs x are not part of the hot path")
+        need_grad = any(ctx.needs_input_grad)
+        out, jitter = _evaluate(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, need_grad)
+        ctx.jitter_used = jitter
+        ctx.shapes = (y.shape, None if mean is None else mean.shape, None if noise_vec is None else noise_vec.shape,
+                      None if noise_scalar is None else noise_scalar.shape, w.shape, mu.shape, v.shape)
+        ctx.dtypes = (y.dtype, mean.dtype, None if noise_vec is None else noise_vec.dtype,
+                      None if noise_scalar is None else noise_scalar.dtype, w.dtype, mu.dtype, v.dtype)
+        if need_grad:
+            ctx.save_for_backward(out["g_w"], out["g_mu"], out["g_v"], out["g_noise"], out["g_mean"])
+        SMExactMLLFunction.last_jitter = jitter
+        return out["mll"].to(w.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g_w, g_mu, g_v, g_noise, g_mean = ctx.saved_tensors
+        ys, ms, nvs, nss, wsh, mush, vsh = ctx.shapes
+        yd, md, nvd, nsd, wd, mud, vd = ctx.dtypes
+        go = gout.to(torch.float64)
+        gb = go.unsqueeze(-1) if go.dim() > 0 else go          # broadcast over the trailing data/param dim
+        need = ctx.needs_input_grad
+        gy = (-(g_mean * gb)).reshape(ys).to(yd) if need[1] else None
+        gm = (g_mean * gb).reshape(ys).sum_to_size(ms).to(md) if need[2] else None
+        gnv = (g_noise * gb).reshape(ys).sum_to_size(nvs).to(nvd) if (nvs is not None and need[3]) else None
+        gns = None
+        if nss is not None and need[4]:
+            gns = (g_noise.sum(-1) * go).reshape(nss if len(nss) else ()).to(nsd)
+        gw = (g_w * gb).reshape(wsh).to(wd) if need[5] else None
+        gbb = gb.unsqueeze(-1) if go.dim() > 0 else go
+        gmu = (g_mu * gbb).reshape(mush).to(mud) if need[6] else None
+        gv = (g_v * gbb).reshape(vsh).to(vd) if need[7] else None
+        return None, gy, gm, gnv, gns, gw, gmu, gv, None
+
+
+SMExactMLLFunction.last_jitter = 0.0
+
+
+def sm_exact_mll(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order=0):
+    return SMExactMLLFunction.apply(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order)

@@ -1,0 +1,48 @@
+"""TEST-ONLY stand-in for ``pgmuvi_amd._hip.mll_value_grad`` built on the CPU oracle.
+
+Used (via unittest.mock.patch) by the ``not gpu`` tests to exercise the host logic --
+the GPyTorch-shaped surface, the autograd node, the trainer, the batch sharding and the
+drop-in with the reference's own ``pgmuvi`` package -- in a container without a GPU.
+The product never imports this; GPU tests compare the real HIP path with the oracle.
+"""
+import torch
+
+from oracle import sm_mll_oracle as orc
+
+
+def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitter=0.0, need_grad=True, workspace=None):
+    batched = y.dim() == 2
+    B = y.shape[0] if batched else 1
+    n = y.shape[-1]
+    D = torch.float64
+    xd = x.detach().to(D).reshape(B, n, -1)
+    d = xd.shape[-1]
+    q = w.shape[-1]
+    yd = y.detach().to(D).reshape(B, n)
+    md = mean.detach().to(D).expand(y.shape).reshape(B, n)
+    nz = None if noise is None else noise.detach().to(D).expand(y.shape).reshape(B, n)
+    ns = None if noise_scalar is None else torch.as_tensor(noise_scalar).detach().to(D).expand(B).reshape(B)
+    wd, mud, vd = w.detach().to(D).reshape(B, q), mu.detach().to(D).reshape(B, q, d), v.detach().to(D).reshape(B, q, d)
+    keys = ["mll", "info", "g_w", "g_mu", "g_v", "g_noise", "g_mean"]
+    res = {k: [] for k in keys}
+    for b in range(B):
+        nv = torch.zeros(n, dtype=D) if nz is None else nz[b]
+        if ns is not None:
+            nv = nv + ns[b]
+        try:
+            val, g = orc.mll_value_grad_closed_form(xd[b], yd[b], md[b], nv, wd[b], mud[b], vd[b], dim_order, jitter)
+            info = 0
+        except Exception:                              # torch.linalg.cholesky failure = non-PD
+            val = torch.tensor(float("nan"), dtype=D)
+            g = dict(w=torch.zeros(q, dtype=D), mu=torch.zeros(q, d, dtype=D), v=torch.zeros(q, d, dtype=D),
+                     noise=torch.zeros(n, dtype=D), mean=torch.zeros(n, dtype=D))
+            info = 1
+        res["mll"].append(val.reshape(())); res["info"].append(torch.tensor(info, dtype=torch.int32))
+        res["g_w"].append(g["w"]); res["g_mu"].append(g["mu"].reshape(q, d)); res["g_v"].append(g["v"].reshape(q, d))
+        res["g_noise"].append(g["noise"].reshape(n)); res["g_mean"].append(g["mean"])
+    out = {k: torch.stack(vs) for k, vs in res.items()}
+    if not batched:
+        out = {k: t[0] for k, t in out.items()}
+    out = {k: t.to(y.device) for k, t in out.items()}
+    out["workspace"] = None
+    return out
