@@ -56,7 +56,12 @@ def cpu_baseline(n, reps):
     host cores: value + gradient by autograd through the dense graph, as loss.backward()
     does in the reference."""
     from oracle import sm_mll_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
     t, y, e = syn.cfg2(n_obs=n)
     x64, y64, nz = t.double(), y.double(), e.double() ** 2
     h = syn.cfg_hypers(2, y64)

@@ -144,111 +144,285 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
 }
 
 // ---------------------------------------------------------------------------
-// Diagonal block k:  U_kk = chol_upper(A_kk), Uinv_kk and its transpose, the
-// block's share of log det, z_k = Uinv_kk^T r_k and alpha_k = Uinv_kk z_k.
-// Register-resident elimination: thread (ti,tj) of a 16x16 grid owns the 8x8
-// elements (ti+16a, tj+16b) of A_kk and of the evolving inverse factor; only the
-// pivot row travels through LDS (double-buffered, one barrier per column).
+// Diagonal block k (128x128, on the critical path of every step):
+//   U_kk = chol_upper(A_kk),  V_kk = U_kk^-T (both orientations, for the row solve),
+//   the block's share of log det,  z_k = V_kk r_k  and  alpha_k = V_kk^T z_k.
+// The block lives in LDS and is processed as 8x8 sub-blocks of 16x16 -- the same
+// right-looking sweep as the outer algorithm, one level down:
+//   (a) one wavefront factors the 16x16 diagonal sub-block in registers (a column per
+//       lane; lanes 16-31 carry the identity so the same instruction stream yields the
+//       inverse factor), pivots broadcast with v_readlane;
+//   (b) the other sub-blocks of block row s are multiplied by that inverse (MFMA);
+//   (c) trailing sub-blocks T_ij -= U_si^T U_sj and R_ij -= U_si^T V_sj (MFMA), while
+//       wave 0 already factors the next diagonal sub-block (look-ahead).
+// T (upper) and the evolving inverse factor (strictly lower) share one LDS image.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void k_diag(PgmDev P, int k) {
+constexpr int DB = 16;
+constexpr int PM = NB + 16;
+constexpr int DIAG_THREADS = 512;
+
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d): hardware seed + one Newton step (relative error ~1e-15)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-d * y, y, 1.0);
+  return __builtin_fma(0.5 * y, e, y);
+}
+
+struct DiagCtx {
+  double* M;        // LDS image [NB][PM]
+  double* uiS;      // uiS[k*16+m] = V_ss[m][k]
+  double* udg;      // U_pp (square roots of the pivots)
+  double* pbuf;     // [4][32] mini-panel exchange buffer
+  double* Akk;      // global diagonal block of the matrix
+  int64_t ld;
+  double* Dinv0;    // global Uinv  [p][m]
+  double* Dinv1;    // global Uinv^T = V [k][n]
+  int* info;
+  int kbase;        // k * NB (for the failure index)
+  double* dump;     // LDS scratch (one slot per lane) that absorbs predicated-off stores
+};
+
+// LDS-only barrier: global stores issued earlier keep draining in the background
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// (a) one wavefront: Cholesky of the 16x16 sub-block s plus its inverse factor.
+// The block and an identity (whose image under the same row operations is V = u^-T)
+// are held in the f64 MFMA C layout (lane (g, n) = rows g+4r of column n).  Pivots go
+// in mini-panels of 4 rows: the panel is exchanged through LDS so that every lane
+// holds the 4 panel rows of its column, is factored with uniform multipliers
+// (v_readlane), and the rank-4 trailing update of both images is one MFMA each:
+//   acc -= P^T P  ==  mfma(-row, row, acc)   (the panel row IS the A and B fragment).
+__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane) {
+  const int g = lane >> 4, n = lane & 15;
+  double* Mb = c.M + (s * DB) * PM + s * DB;
+  double* pbuf = c.pbuf;                      // [4][32]
+  v4d ua, va;                                 // A image, identity image (C layout)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ua[r] = Mb[(g + 4 * r) * PM + n];
+    va[r] = (g + 4 * r == n) ? 1.0 : 0.0;
+  }
+  double fa[4], fb[4];
+  int failp = -1;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    pbuf[g * 32 + n] = ua[m];
+    pbuf[g * 32 + 16 + n] = va[m];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double pa[4], pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { pa[q] = pbuf[q * 32 + n]; pb[q] = pbuf[q * 32 + 16 + n]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+      double dp = readlane_d(pa[pl], 4 * m + pl);
+      const bool bad = !(dp > 0.0);
+      failp = (bad && failp < 0) ? (4 * m + pl) : failp;
+      dp = bad ? 1.0 : dp;
+      const double rs = rsqrt_nr(dp);
+      pa[pl] *= rs;
+      pb[pl] *= rs;
+#pragma unroll
+      for (int ql = pl + 1; ql < 4; ++ql) {
+        const double mult = readlane_d(pa[pl], 4 * m + ql);
+        pa[ql] = __builtin_fma(-mult, pa[pl], pa[ql]);
+        pb[ql] = __builtin_fma(-mult, pb[pl], pb[ql]);
+      }
+    }
+    const double ra = (g == 0) ? pa[0] : (g == 1) ? pa[1] : (g == 2) ? pa[2] : pa[3];
+    const double rb = (g == 0) ? pb[0] : (g == 1) ? pb[1] : (g == 2) ? pb[2] : pb[3];
+    fa[m] = ra;
+    fb[m] = rb;
+    if (m < 3) {
+      ua = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, ra, ua, 0, 0, 0);
+      va = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, rb, va, 0, 0, 0);
+    }
+  }
+  double* mydump = c.dump + lane;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    Mb[i * PM + n] = (n > i) ? fa[r] : fb[r];     // u strictly above the diagonal, V on and below
+    c.uiS[n * DB + i] = fb[r];                     // uiS[k*16+m] = V[m][k]; V is 0 above its diagonal
+    double* dst = (n == i) ? (c.udg + s * DB + i) : mydump;
+    *dst = fa[r];                                  // U_ii = sqrt(pivot)
+  }
+  if (failp >= 0 && lane == 0 && *c.info == 0) *c.info = c.kbase + s * DB + failp + 1;
+}
+
+// results of sub-block s that live on the diagonal: u (strictly upper + sqrt of the
+// pivots) to the matrix, V_ss to both inverse images; one wavefront, 4 elements per lane
+__device__ __forceinline__ void diag_store_diagblock(const DiagCtx& c, int s, int lane) {
+  const int kq = lane >> 4, n = lane & 15;
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) {
+    const int i = kq + 4 * r2;
+    const double v = c.M[(s * DB + i) * PM + s * DB + n];
+    const int gi = s * DB + i, gj = s * DB + n;
+    if (n > i) c.Akk[(int64_t)gi * c.ld + gj] = v;
+    else {
+      if (n == i) c.Akk[(int64_t)gi * c.ld + gj] = c.udg[gi];
+      c.Dinv1[gi * NB + gj] = v;
+      c.Dinv0[gj * NB + gi] = v;
+    }
+  }
+}
+
+// (b) X(s,j) <- V_ss X(s,j), in place; finished rows go straight to global memory
+__device__ __forceinline__ void diag_rowsolve(const DiagCtx& c, int s, int j, int lane) {
+  const int kq = lane >> 4, n = lane & 15;
+  double b[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b[r] = c.M[(s * DB + 4 * r + kq) * PM + j * DB + n];
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c.uiS[(4 * r + kq) * DB + n], b[r], acc, 0, 0, 0);
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) {
+    const int row = s * DB + kq + 4 * r2, colg = j * DB + n;
+    c.M[row * PM + colg] = acc[r2];
+    if (j > s) {
+      c.Akk[(int64_t)row * c.ld + colg] = acc[r2];       // U_kk block (s,j)
+    } else {
+      c.Dinv1[row * NB + colg] = acc[r2];                // V row-major
+      c.Dinv0[colg * NB + row] = acc[r2];                // and transposed (Uinv)
+    }
+  }
+}
+
+// (c) C(i,j) <- C(i,j) - U(s,i)^T B(s,j);  B is U(s,j) (j>s), V(s,j) (j<s) or V_ss (j==s)
+__device__ __forceinline__ void diag_update(const DiagCtx& c, int s, int i, int j, int lane) {
+  const int kq = lane >> 4, n = lane & 15;
+  v4d acc;
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) acc[r2] = (j == s) ? 0.0 : c.M[(i * DB + kq + 4 * r2) * PM + j * DB + n];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int krow = s * DB + 4 * r + kq;
+    const double av = -c.M[krow * PM + i * DB + n];
+    double bv = c.M[krow * PM + j * DB + n];
+    if (j == s && n > 4 * r + kq) bv = 0.0;              // V_ss is lower triangular; above it sits u
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) c.M[(i * DB + kq + 4 * r2) * PM + j * DB + n] = acc[r2];
+}
+
+__global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
-  double* A = P.A + b * P.sA;
-  double* Akk = A + (int64_t)k * NB * P.ld + k * NB;
-  constexpr int VP = NB + 1;
-  __shared__ double Vs[NB * VP];
-  __shared__ double rowT[2][NB], rowR[2][NB], dbuf[NB], zs[NB], rs[NB], red[4];
-  const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
-  double Tm[8][8], Rm[8][8];
+  __shared__ __attribute__((aligned(16))) double M[NB * PM];
+  __shared__ double uiS[DB * DB];
+  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], red[8], dump[64], pbuf[4 * 32];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  DiagCtx c;
+  c.M = M; c.uiS = uiS; c.udg = udg; c.dump = dump; c.pbuf = pbuf;
+  c.Akk = P.A + b * P.sA + (int64_t)k * NB * P.ld + k * NB;
+  c.ld = P.ld;
+  c.Dinv0 = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+  c.Dinv1 = c.Dinv0 + NB * NB;
+  c.info = P.info + b;
+  c.kbase = k * NB;
+  // load the block (upper part is meaningful), clear the inverse images, fetch r_k
+  for (int e = t; e < NB * NB / 2; e += DIAG_THREADS) {
+    const int row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+    *reinterpret_cast<v2d*>(M + row * PM + c2) = *reinterpret_cast<const v2d*>(c.Akk + (int64_t)row * P.ld + c2);
+  }   // (the zero triangles of the inverse images are cleared once, at workspace creation)
+  if (t < NB) { rsv[t] = P.r[b * P.sVec + k * NB + t]; alv[t] = 0.0; }
+  __syncthreads();
+#ifdef PGM_DIAG_STAMPS
+  long long st_[40]; int sn_ = 0;
+#define STAMP() do { if (sn_ < 40) st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+  if (wave == 0) diag_potrf16(c, 0, lane);
+  STAMP();
+  constexpr int NS = NB / DB;
+  for (int s = 0; s < NS; ++s) {
+    lds_barrier();
+    STAMP();
+    // ---- (b) block row s
+    if (wave < NS - 1) {
+      const int j = (wave < s) ? wave : wave + 1;
+      diag_rowsolve(c, s, j, lane);
+    } else {
+      if (lane < DB) {
+        double acc = 0.0;
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int i = ti + 16 * a, j = tj + 16 * c;
-      Tm[a][c] = (c >= a) ? Akk[(int64_t)i * P.ld + j] : 0.0;
-      Rm[a][c] = (i == j) ? 1.0 : 0.0;
+        for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
+        zsv[s * DB + lane] = acc;
+      }
+      diag_store_diagblock(c, s, lane);
     }
-  if (t < NB) rs[t] = P.r[b * P.sVec + k * NB + t];
-
-  for (int p = 0; p < NB; ++p) {
-    const int pa = p >> 4, pt = p & 15, buf = p & 1;
-    if (ti == pt) {
+    lds_barrier();
+    STAMP();
+    // ---- (c) trailing sub-blocks; wave 0 runs ahead on the next diagonal sub-block
+    if (wave == 0) {
+      if (s + 1 < NS) {
+        diag_update(c, s, s + 1, s + 1, lane);
+        STAMP();
+        diag_potrf16(c, s + 1, lane);
+        STAMP();
+      }
+    } else {
+      if (wave == NS - 1) {
+        // forward substitution / alpha ride along: 2 columns per lane
 #pragma unroll
-      for (int a = 0; a < 8; ++a)
-        if (a == pa) {
+        for (int u = 0; u < 2; ++u) {
+          const int colg = lane + 64 * u, jb = colg / DB;
+          double acc = 0.0;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            rowT[buf][tj + 16 * c] = Tm[a][c];
-            rowR[buf][tj + 16 * c] = Rm[a][c];
+          for (int m = 0; m < DB; ++m) {
+            double v = M[(s * DB + m) * PM + colg];
+            if (jb == s && (colg - s * DB) > m) v = 0.0;
+            acc += v * zsv[s * DB + m];
           }
+          if (jb > s) rsv[colg] -= acc; else alv[colg] += acc;
         }
-    }
-    __syncthreads();
-    double dpiv = rowT[buf][p];
-    if (!(dpiv > 0.0)) {
-      if (t == 0 && P.info[b] == 0) P.info[b] = k * NB + p + 1;
-      dpiv = 1.0;
-    }
-    if (t == 0) dbuf[p] = dpiv;
-    const double rinv = 1.0 / dpiv;
-    double lj[8], rj[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      lj[c] = rowT[buf][tj + 16 * c];
-      rj[c] = rowR[buf][tj + 16 * c];
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      if (a >= pa) {
-        const int i = ti + 16 * a;
-        const double li = (i > p) ? rowT[buf][i] * rinv : 0.0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (c >= a) Tm[a][c] -= li * lj[c];
-          if (c <= pa) Rm[a][c] -= li * rj[c];
+      }
+      const int nrem = NS - 1 - s;
+      const int nT = nrem * (nrem + 1) / 2, nR = nrem * (s + 1);
+      for (int idx = wave - 1; idx < nT + nR; idx += NS - 1) {
+        int i, j;
+        if (idx < nT) {
+          tri_decode(idx, i, j);
+          i += s + 1; j += s + 1;
+          if (i == s + 1 && j == s + 1) continue;       // done by wave 0
+        } else {
+          const int t2 = idx - nT;
+          i = s + 1 + t2 / (s + 1);
+          j = t2 % (s + 1);
         }
+        diag_update(c, s, i, j, lane);
       }
     }
   }
   __syncthreads();
-  // scale rows by d_i^-1/2; U to the matrix, V = Uinv^T to LDS
-  double* Dk = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    const int i = ti + 16 * a;
-    const double sc = 1.0 / sqrt(dbuf[i]);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int j = tj + 16 * c;
-      Akk[(int64_t)i * P.ld + j] = (j >= i) ? Tm[a][c] * sc : 0.0;
-      Vs[i * VP + j] = (j <= i) ? Rm[a][c] * sc : 0.0;
-    }
-  }
-  __syncthreads();
-  {
-    const int cidx = t & 127, r0 = t >> 7;
-    for (int s = 0; s < NB / 2; ++s) {
-      const int rrow = r0 + 2 * s;
-      Dk[NB * NB + rrow * NB + cidx] = Vs[rrow * VP + cidx];   // Uinv^T = V_kk, [k][n]
-      Dk[rrow * NB + cidx] = Vs[cidx * VP + rrow];             // Uinv [p][m] = V[m][p]
-    }
-  }
   if (t < NB) {
-    double acc = 0.0;
-    for (int j = 0; j <= t; ++j) acc += Vs[t * VP + j] * rs[j];
-    zs[t] = acc;
-    P.z[b * P.sVec + k * NB + t] = acc;
+    P.z[b * P.sVec + k * NB + t] = zsv[t];
+    P.alpha[b * P.sVec + k * NB + t] = alv[t];
   }
-  double lg = (t < NB) ? log(dbuf[t]) : 0.0;
+  double lg = (t < NB) ? 2.0 * log(udg[t]) : 0.0;
   lg = wave_sum(lg);
-  if ((t & 63) == 0) red[t >> 6] = lg;
+  if (lane == 0) red[wave] = lg;
   __syncthreads();
-  if (t < NB) {
-    double acc = 0.0;
-    for (int i = t; i < NB; ++i) acc += Vs[i * VP + t] * zs[i];
-    P.alpha[b * P.sVec + k * NB + t] = acc;
-  }
-  if (t == 0) P.logdet[b * P.sLogdet + k] = red[0] + red[1] + red[2] + red[3];
+  if (t == 0) P.logdet[b * P.sLogdet + k] = red[0] + red[1];
+#ifdef PGM_DIAG_STAMPS
+  STAMP();
+  if (t == 0 && k == 0) { for (int q = 0; q < sn_; ++q) P.partials[q] = (double)(st_[q] - st_[0]); P.partials[40] = sn_; }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -258,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void k_diag(PgmDev P, int k) {
 // so does alpha,  alpha_j += V_kj^T z_k  (j < k).
 // ---------------------------------------------------------------------------
 using CfgTrsm = TileCfg<128, 32, 32, 32>;
-__global__ __launch_bounds__(256) void k_trsm(PgmDev P, int k) {
+__global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
   using C = CfgTrsm;
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
@@ -306,7 +480,7 @@ __global__ __launch_bounds__(256) void k_trsm(PgmDev P, int k) {
 //   R_ij -= U_ki^T V_kj   i > k >= j           (inverse factor, same sweep)
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256) void k_update(PgmDev P, int k) {
+__global__ __launch_bounds__(256, 2) void k_update(PgmDev P, int k) {
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
   constexpr int SUB = NB / C::BM;
@@ -348,11 +522,14 @@ __global__ __launch_bounds__(256) void k_update(PgmDev P, int k) {
 // ---------------------------------------------------------------------------
 using CfgBig = TileCfg<128, 128, 64, 64>;
 using CfgSmall = TileCfg<64, 64, 32, 32>;
-constexpr int LAUUM_LDS_DOUBLES = 2 * (3 * PGM_MAX_QD + PGM_MAX_D) * NB + 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);
-static_assert(LAUUM_LDS_DOUBLES >= CfgBig::LDS_DOUBLES, "epilogue scratch must cover the GEMM stages");
+// The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
+// a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
+constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);          // alpha slices, weights, wave partials
+constexpr int EPI_SLOTS = (CfgBig::LDS_DOUBLES - EPI_FIXED) / (2 * NB);             // staged factor rows (of 128) per side
+static_assert(EPI_SLOTS >= 3 * 2 + 2, "epilogue staging needs room for one 2-D mixture");
 
 template <int D, int ORDER>
-__global__ __launch_bounds__(256, 1) void k_lauum_grad(PgmDev P) {
+__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   using C = CfgBig;
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
@@ -361,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void k_lauum_grad(PgmDev P) {
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
-  __shared__ __attribute__((aligned(16))) double lds[LAUUM_LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   v4d acc[C::TM][C::TN];
   acc_zero<C>(acc);
   gemm_tn<C>(lds, P.nb - j, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
@@ -374,40 +551,42 @@ __global__ __launch_bounds__(256, 1) void k_lauum_grad(PgmDev P) {
 
   // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
   const int Q = P.q;
-  double* rowd = lds;
-  double* cold = rowd + P.pre_slots * NB;
-  double* arow = cold + P.pre_slots * NB;
+  constexpr int QC = (EPI_SLOTS - D) / (3 * D);          // mixtures staged at once
+  const int nchunks = (Q + QC - 1) / QC;
+  double* arow = lds;
   double* acol = arow + NB;
   double* wl = acol + NB;
-  double* wpart = wl + PGM_MAX_QD;            // [4][nslot]
-  stage_factors(P, P.pre + b * P.sPre, i, j, rowd, cold);
+  double* wpart = wl + PGM_MAX_QD;                       // [4][nslot]
+  double* rowd = lds + EPI_FIXED;                        // [3*qc*D + D][NB]: cos, sin, x*v per (q,d) then raw x per d
+  double* cold = rowd + EPI_SLOTS * NB;
+  const double* pre = P.pre + b * P.sPre;
+  auto stage = [&](int q0, int qc) {                      // uniform across the workgroup
+    __syncthreads();
+    const int nfac = 3 * qc * D;
+    for (int e = threadIdx.x; e < (nfac + D) * NB; e += NTHREADS) {
+      const int slot = e / NB, m = e % NB;
+      const int src = (slot < nfac) ? (3 * q0 * D + slot) : (3 * P.qd + (slot - nfac));
+      rowd[e] = pre[(int64_t)src * P.np + i * NB + m];
+      cold[e] = pre[(int64_t)src * P.np + j * NB + m];
+    }
+    __syncthreads();
+  };
   if (threadIdx.x < NB) {
     arow[threadIdx.x] = P.alpha[b * P.sVec + i * NB + threadIdx.x];
     acol[threadIdx.x] = P.alpha[b * P.sVec + j * NB + threadIdx.x];
   }
   if (threadIdx.x < Q) wl[threadIdx.x] = P.w[(int64_t)b * P.q + threadIdx.x];
   for (int e = threadIdx.x; e < 4 * P.nslot; e += NTHREADS) wpart[e] = 0.0;
-  __syncthreads();
+  if (nchunks == 1) stage(0, Q); else __syncthreads();
 
   const WavePos wp = wave_pos<C>();
   const double sym = (i == j) ? 1.0 : 2.0;
   const double half_n = 0.5 / (double)P.n;
   double* mypart = wpart + wp.wave * P.nslot;
-  const double* rowx = rowd + 3 * P.qd * NB;
-  const double* colx = cold + 3 * P.qd * NB;
   double gns = 0.0;
-#pragma unroll 1
-  for (int ti = 0; ti < C::TM; ++ti) {
-    double Gw[C::TN][4];
-    double Sd[D][C::TN][4];
-    // runtime ti would index acc dynamically: select statically
-    v4d accrow[C::TN];
+  // acc <- sym * G = sym * (alpha alpha^T - A^-1), in place; the diagonal of G is the noise gradient
 #pragma unroll
-    for (int tt = 0; tt < C::TM; ++tt)
-      if (tt == ti) {
-#pragma unroll
-        for (int tj = 0; tj < C::TN; ++tj) accrow[tj] = acc[tt][tj];
-      }
+  for (int ti = 0; ti < C::TM; ++ti)
 #pragma unroll
     for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
@@ -415,12 +594,22 @@ __global__ __launch_bounds__(256, 1) void k_lauum_grad(PgmDev P) {
         const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
         const int gi = i * NB + m, gj = j * NB + n;
         const bool valid = (gi < P.n) && (gj < P.n);
-        const double g = valid ? (arow[m] * acol[n] - accrow[tj][r]) : 0.0;
-        Gw[tj][r] = sym * g;
+        const double g = valid ? (arow[m] * acol[n] - acc[ti][tj][r]) : 0.0;
+        acc[ti][tj][r] = sym * g;
         if (i == j && m == n && valid) {
           gns += g;
           if (P.g_noise) P.g_noise[(int64_t)b * P.n + gi] = half_n * g;
         }
+      }
+#pragma unroll 1
+  for (int ti = 0; ti < C::TM; ++ti) {
+    double Sd[D][C::TN][4];
+    v4d Gw[C::TN];                 // this ti's row of G tiles (runtime ti: select statically)
+#pragma unroll
+    for (int tt = 0; tt < C::TM; ++tt)
+      if (tt == ti) {
+#pragma unroll
+        for (int tj = 0; tj < C::TN; ++tj) Gw[tj] = acc[tt][tj];
       }
     if (D == 2 && ORDER == 0) {
 #pragma unroll
@@ -429,73 +618,84 @@ __global__ __launch_bounds__(256, 1) void k_lauum_grad(PgmDev P) {
         for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
           for (int r = 0; r < 4; ++r) Sd[dd][tj][r] = 0.0;
-      for (int q = 0; q < Q; ++q) {
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const int q0 = ch * QC, qc = min(QC, Q - q0);
+        if (nchunks > 1) stage(q0, qc);
+        for (int ql = 0; ql < qc; ++ql) {
 #pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-          const int qd = q * D + dd;
+          for (int dd = 0; dd < D; ++dd) {
+            const int qd = ql * D + dd;
 #pragma unroll
-          for (int tj = 0; tj < C::TN; ++tj)
+            for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
-              const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-              const double e = exp(-TWO_PI_SQ * ds * ds);
-              const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
-                                rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
-              Sd[dd][tj][r] += wl[q] * e * cc;
-            }
+              for (int r = 0; r < 4; ++r) {
+                const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+                const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
+                const double e = exp(-TWO_PI_SQ * ds * ds);
+                const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
+                                  rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
+                Sd[dd][tj][r] += wl[q0 + ql] * e * cc;
+              }
+          }
         }
       }
     }
-    for (int q = 0; q < Q; ++q) {
-      double gw = 0.0, gmu[D], gv[D];
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int q0 = ch * QC, qc = min(QC, Q - q0);
+      if (nchunks > 1) stage(q0, qc);
+      const double* rowx = rowd + 3 * qc * D * NB;
+      const double* colx = cold + 3 * qc * D * NB;
+      for (int ql = 0; ql < qc; ++ql) {
+        const int q = q0 + ql;
+        double gw = 0.0, gmu[D], gv[D];
 #pragma unroll
-      for (int dd = 0; dd < D; ++dd) { gmu[dd] = 0.0; gv[dd] = 0.0; }
+        for (int dd = 0; dd < D; ++dd) { gmu[dd] = 0.0; gv[dd] = 0.0; }
 #pragma unroll
-      for (int tj = 0; tj < C::TN; ++tj)
+        for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
-          double E[D], CC[D], SN[D], TAU[D];
-#pragma unroll
-          for (int dd = 0; dd < D; ++dd) {
-            const int qd = q * D + dd;
-            const double rc = rowd[(qd * 3 + 0) * NB + m], rsn = rowd[(qd * 3 + 1) * NB + m];
-            const double cc_ = cold[(qd * 3 + 0) * NB + n], cs_ = cold[(qd * 3 + 1) * NB + n];
-            const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-            E[dd] = exp(-TWO_PI_SQ * ds * ds);
-            CC[dd] = rc * cc_ + rsn * cs_;
-            SN[dd] = rsn * cc_ - rc * cs_;
-            TAU[dd] = rowx[dd * NB + m] - colx[dd * NB + n];
-          }
-          const double G = Gw[tj][r];
-          if (D == 1) {
-            const double GE = G * E[0];
-            gw += GE * CC[0];
-            gmu[0] += GE * SN[0] * TAU[0];
-            gv[0] += GE * CC[0] * TAU[0] * TAU[0];
-          } else {
+          for (int r = 0; r < 4; ++r) {
+            const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+            double E[D], CC[D], SN[D], TAU[D];
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
-              const int o = (D == 2) ? 1 - dd : 0;
-              const double oth = (ORDER == 0) ? Sd[o][tj][r] : E[o] * CC[o];
-              const double GE = G * oth * E[dd];
-              if (ORDER == 0) gw += GE * CC[dd];
-              gmu[dd] += GE * SN[dd] * TAU[dd];
-              gv[dd] += GE * CC[dd] * TAU[dd] * TAU[dd];
+              const int qd = ql * D + dd;
+              const double rc = rowd[(qd * 3 + 0) * NB + m], rsn = rowd[(qd * 3 + 1) * NB + m];
+              const double cc_ = cold[(qd * 3 + 0) * NB + n], cs_ = cold[(qd * 3 + 1) * NB + n];
+              const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
+              E[dd] = exp(-TWO_PI_SQ * ds * ds);
+              CC[dd] = rc * cc_ + rsn * cs_;
+              SN[dd] = rsn * cc_ - rc * cs_;
+              TAU[dd] = rowx[dd * NB + m] - colx[dd * NB + n];
             }
-            if (ORDER != 0) gw += G * E[0] * CC[0] * E[1 % D] * CC[1 % D];
+            const double G = Gw[tj][r];
+            if (D == 1) {
+              const double GE = G * E[0];
+              gw += GE * CC[0];
+              gmu[0] += GE * SN[0] * TAU[0];
+              gv[0] += GE * CC[0] * TAU[0] * TAU[0];
+            } else {
+#pragma unroll
+              for (int dd = 0; dd < D; ++dd) {
+                const int o = (D == 2) ? 1 - dd : 0;
+                const double oth = (ORDER == 0) ? Sd[o][tj][r] : E[o] * CC[o];
+                const double GE = G * oth * E[dd];
+                if (ORDER == 0) gw += GE * CC[dd];
+                gmu[dd] += GE * SN[dd] * TAU[dd];
+                gv[dd] += GE * CC[dd] * TAU[dd] * TAU[dd];
+              }
+              if (ORDER != 0) gw += G * E[0] * CC[0] * E[1 % D] * CC[1 % D];
+            }
           }
-        }
-      gw = wave_sum(gw);
+        gw = wave_sum(gw);
 #pragma unroll
-      for (int dd = 0; dd < D; ++dd) { gmu[dd] = wave_sum(gmu[dd]); gv[dd] = wave_sum(gv[dd]); }
-      if (wp.lane == 0) {
-        mypart[q] += gw;
+        for (int dd = 0; dd < D; ++dd) { gmu[dd] = wave_sum(gmu[dd]); gv[dd] = wave_sum(gv[dd]); }
+        if (wp.lane == 0) {
+          mypart[q] += gw;
 #pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-          mypart[Q + q * D + dd] += gmu[dd];
-          mypart[Q + Q * D + q * D + dd] += gv[dd];
+          for (int dd = 0; dd < D; ++dd) {
+            mypart[Q + q * D + dd] += gmu[dd];
+            mypart[Q + Q * D + q * D + dd] += gv[dd];
+          }
         }
       }
     }
@@ -628,7 +828,7 @@ __global__ __launch_bounds__(256) void k_pred_cross(PgmDev P, const double* __re
   }
 }
 
-__global__ __launch_bounds__(256) void k_pred_trsm(PgmDev P, int k, double* Ks, int64_t Mp) {
+__global__ __launch_bounds__(256, 2) void k_pred_trsm(PgmDev P, int k, double* Ks, int64_t Mp) {
   using C = CfgTrsm;
   double* Cb = Ks + (int64_t)k * NB * Mp + (int64_t)blockIdx.x * C::BN;
   const double* Uinv = P.Dinv + (int64_t)k * 2 * NB * NB;
@@ -641,7 +841,7 @@ __global__ __launch_bounds__(256) void k_pred_trsm(PgmDev P, int k, double* Ks, 
   acc_store<C>(Cb, Mp, acc, 1.0);
 }
 
-__global__ __launch_bounds__(256) void k_pred_update(PgmDev P, int k, double* Ks, int64_t Mp) {
+__global__ __launch_bounds__(256, 2) void k_pred_update(PgmDev P, int k, double* Ks, int64_t Mp) {
   using C = CfgBig;
   const int i = k + 1 + blockIdx.y;
   const double* pa0 = P.A + (int64_t)k * NB * P.ld + i * NB;
@@ -676,7 +876,8 @@ __global__ __launch_bounds__(256) void k_pred_reduce(PgmDev P, const double* __r
   if (var_out) var_out[m] = kss - s2;
 }
 
-// back-to-back fp64 MFMA issue probe
+// back-to-back fp64 MFMA issue probe: accumulators pinned to VGPRs (the AGPR form of
+// v_mfma_f64_16x16x4_f64 issues at half rate on gfx950)
 __global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
   v4d acc[8];
 #pragma unroll
@@ -684,7 +885,7 @@ __global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
   double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[u], 0, 0, 0);
+    for (int u = 0; u < 8; ++u) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(bb));
   }
   double s = 0.0;
 #pragma unroll
