@@ -1,0 +1,84 @@
+"""Drop-in check with the reference's OWN code (CPU, this container only).
+
+``pgmuvi_amd.install_as_gpytorch()`` registers the shim as ``gpytorch``; then the
+reference package itself -- ``/root/reference/pgmuvi`` (``gps.py``, ``trainers.py``,
+``lightcurve.py``) -- is imported unmodified and ``Lightcurve.fit()`` is driven through
+it.  There is no GPU here, so the one HIP call is replaced (in the test only) by the
+oracle stand-in; the GPU tests establish HIP == oracle separately.  Skipped wherever
+``/root/reference`` does not exist (e.g. on the GPU box)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pgmuvi")), reason="reference checkout not present")
+
+
+def _run(body):
+    """Own interpreter: the shim replaces ``gpytorch`` in sys.modules process-wide."""
+    prog = textwrap.dedent("""
+        import sys, warnings, torch, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from unittest import mock
+        import pgmuvi_amd
+        from pgmuvi_amd import _hip, synthetic as syn
+        import _oracle_backend as ob
+        pgmuvi_amd.install_as_gpytorch()
+        warnings.simplefilter("ignore")
+    """ % (ROOT, os.path.join(ROOT, "tests"), REF)) + textwrap.dedent(body)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_reference_modules_import_against_the_shim():
+    out = _run("""
+        import gpytorch, pgmuvi.gps as gps, pgmuvi.trainers, pgmuvi.lightcurve, pgmuvi.constraints, pgmuvi.priors
+        assert gpytorch is pgmuvi_amd.gpytorch
+        m = gps.SpectralMixtureGPModel(torch.linspace(0, 1, 20), torch.zeros(20), gpytorch.likelihoods.GaussianLikelihood(), num_mixtures=3)
+        assert m.sci_kernel is m.covar_module and m.covar_module.num_mixtures == 3
+        m2 = gps.TwoDSpectralMixtureGPModel(torch.rand(20, 2), torch.zeros(20), gpytorch.likelihoods.GaussianLikelihood(), num_mixtures=2)
+        assert m2.covar_module.ard_num_dims == 2 and m2.covar_module.raw_mixture_means.shape == (2, 1, 2)
+        print("IMPORT_OK")
+    """)
+    assert "IMPORT_OK" in out
+
+
+def test_reference_lightcurve_fit_1d_runs_through_the_shim():
+    out = _run("""
+        from pgmuvi.lightcurve import Lightcurve
+        t, y, e = syn.cfg2(n_obs=60)
+        with mock.patch.object(_hip, "mll_value_grad", ob.mll_value_grad):
+            lc = Lightcurve(t, y, yerr=e, max_samples=None)
+            res = lc.fit(model="1D", num_mixtures=2, periods=[150.0, 67.0], training_iter=8, lr=0.01, stop=None, miniter=1)
+        loss = [float(v) for v in res["loss"]]
+        assert len(loss) == 8 and loss[-1] < loss[0], loss
+        assert set(res) >= {"loss", "delta_loss", "covar_module.mixture_means", "covar_module.mixture_weights", "mean_module.constant"}
+        pars = lc.get_parameters()
+        assert pars["covar_module.mixture_means"].shape == (2, 1, 1)
+        names = [n for n, _ in lc.model.named_parameters()]
+        assert names == ["mean_module.raw_constant", "covar_module.raw_mixture_weights", "covar_module.raw_mixture_means", "covar_module.raw_mixture_scales"]
+        print("FIT1D_OK", loss[0], loss[-1])
+    """)
+    assert "FIT1D_OK" in out
+
+
+def test_reference_lightcurve_fit_2d_and_learned_noise():
+    out = _run("""
+        from pgmuvi.lightcurve import Lightcurve
+        x, y, e = syn.cfg4(n_per_band=10)
+        with mock.patch.object(_hip, "mll_value_grad", ob.mll_value_grad):
+            lc = Lightcurve(x, y, yerr=e, max_samples=None)
+            res = lc.fit(model="2D", num_mixtures=2, use_mls_init=False, training_iter=5, lr=0.01, stop=None, miniter=1)
+            assert len(res["loss"]) == 5 and all(np.isfinite(float(v)) for v in res["loss"])
+            t, y1, _ = syn.cfg2(n_obs=40)
+            lc2 = Lightcurve(t, y1, max_samples=None)          # no yerr -> GaussianLikelihood with a learned noise
+            res2 = lc2.fit(model="1D", num_mixtures=1, periods=[150.0], training_iter=4, lr=0.01, stop=None, miniter=1)
+            assert any("noise" in k for k in res2), list(res2)
+        print("FIT2D_OK")
+    """)
+    assert "FIT2D_OK" in out

@@ -1,0 +1,194 @@
+"""CPU tests of the host logic: the GPyTorch-shaped operator surface, the autograd node,
+the trainer mirror and the no-fallback rule.  Where an evaluation is needed the HIP call
+is replaced -- in the test only -- by the oracle stand-in ``tests/_oracle_backend.py``."""
+import math
+import os
+import re
+import warnings
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle_backend as ob
+from oracle import sm_mll_oracle as orc
+from pgmuvi_amd import _hip, gpytorch as g, synthetic as syn
+from pgmuvi_amd.trainers import train
+
+D = torch.float64
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(x, y, lik, Q=4, d=1, mean="constant"):
+    class Model(g.models.ExactGP):
+        def __init__(self):
+            super().__init__(x, y, lik)
+            self.mean_module = g.means.ConstantMean() if mean == "constant" else g.means.LinearMean(input_size=d)
+            self.covar_module = g.kernels.SpectralMixtureKernel(num_mixtures=Q, ard_num_dims=d)
+            self.sci_kernel = self.covar_module
+
+        def forward(self, xx):
+            return g.distributions.MultivariateNormal(self.mean_module(xx), self.covar_module(xx))
+
+    return Model().double()
+
+
+@pytest.fixture()
+def small():
+    t, y, e = syn.cfg2(n_obs=48)
+    return t.double(), y.double(), e.double() ** 2
+
+
+def test_product_has_no_cpu_fallback_and_never_touches_the_oracle(small):
+    x, y, noise = small
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise)
+    m = _model(x, y, lik)
+    m.train()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g.mlls.ExactMarginalLogLikelihood(lik, m)(m(x), y)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.covar_module(x).to_dense()
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|['\"]oracle['\"]|oracle/", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pgmuvi_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), f"{f} references oracle/"
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with mock.patch.object(_hip, "_lib", None), mock.patch.object(_hip, "_LIB_PATH", str(tmp_path / "nope.so")):
+        with pytest.raises(_hip.HipLibraryMissing):
+            _hip.load()
+
+
+def test_parameter_names_shapes_and_constraints(small):
+    x, y, noise = small
+    lik = g.likelihoods.GaussianLikelihood()
+    m = _model(x, y, lik)
+    names = [n for n, _ in m.named_parameters()]
+    assert names == ["likelihood.noise_covar.raw_noise", "mean_module.raw_constant", "covar_module.raw_mixture_weights",
+                     "covar_module.raw_mixture_means", "covar_module.raw_mixture_scales"]      # pgmuvi/trainers.py:173
+    k = m.covar_module
+    assert k.raw_mixture_weights.shape == (4,) and k.raw_mixture_means.shape == (4, 1, 1) and k.num_mixtures == 4
+    assert abs(float(k.mixture_weights[0]) - math.log(2.0)) < 1e-12          # softplus(0) = 0.6931 (reference notebook)
+    assert float(lik.noise) > 1e-4                                           # GreaterThan(1e-4) default
+    m.mean_module.register_constraint("raw_constant", g.constraints.Interval(-2.0, 3.0))
+    assert "raw_constant_constraint" in m.mean_module._constraints           # reference tests/test_constraint_sets.py:95
+    assert {n for n, _ in m.named_constraints()} >= {"mean_module.raw_constant_constraint", "covar_module.raw_mixture_means_constraint"}
+    c = m.mean_module._constraints["raw_constant_constraint"]
+    c.lower_bound = torch.tensor(-5.0)                                        # pgmuvi mutates bounds (lightcurve.py:3140)
+    assert float(c.lower_bound) == -5.0 and -5.0 < float(m.mean_module.constant) < 3.0
+    with pytest.raises(RuntimeError, match="nonexistent"):
+        m.mean_module.register_constraint("raw_nothing", g.constraints.Positive())
+    with pytest.raises(ValueError):
+        g.constraints.Interval(1.0, 0.0)
+    with pytest.raises(ValueError):
+        g.constraints.Interval(0.0, math.inf)
+
+
+def test_initialize_dotted_names_and_bounds(small):
+    x, y, noise = small
+    m = _model(x, y, g.likelihoods.FixedNoiseGaussianLikelihood(noise))
+    h = syn.cfg_hypers(2, y)
+    m.initialize(**{"covar_module.mixture_means": h["mu"], "covar_module.mixture_scales": h["v"],
+                    "covar_module.mixture_weights": h["w"], "mean_module.constant": 0.25})        # lightcurve.py:4156
+    assert torch.allclose(m.covar_module.mixture_means, h["mu"], rtol=1e-12)
+    assert abs(float(m.mean_module.constant) - 0.25) < 1e-12
+    m.covar_module.register_constraint("raw_mixture_means", g.constraints.GreaterThan(1.0 / 3450.0))
+    m.initialize(**{"covar_module.mixture_means": h["mu"]})
+    assert torch.allclose(m.covar_module.mixture_means, h["mu"], rtol=1e-6)
+    with pytest.raises(AttributeError):
+        m.initialize(**{"covar_module.no_such_thing": 1.0})
+    m.covar_module.initialize_from_data(x, y)                                                    # gps.py:209
+    assert torch.all(m.covar_module.mixture_means > 0) and torch.all(torch.isfinite(m.covar_module.mixture_scales))
+    assert torch.allclose(m.covar_module.mixture_weights, (y.std() / 4).expand(4))
+
+
+def test_out_of_scope_names_import_but_refuse_to_run():
+    from pgmuvi_amd.gpytorch.kernels import GridInterpolationKernel, ScaleKernel, RBFKernel, MaternKernel  # noqa: F401
+    from pgmuvi_amd.gpytorch.variational import CholeskyVariationalDistribution, VariationalStrategy      # noqa: F401
+    with pytest.raises(NotImplementedError):
+        RBFKernel()
+    with pytest.raises(NotImplementedError):
+        g.models.ApproximateGP(None)
+    for ctx in (g.settings.max_cg_iterations(10000), g.settings.fast_pred_var(), g.settings.fast_computations(False, False, False)):
+        with ctx:
+            pass
+    with g.settings.fast_computations(False, False, False):
+        assert g.settings.fast_computations.log_prob.off()
+    assert g.settings.fast_computations.log_prob.on()
+
+
+def test_mll_backward_train_loop_with_oracle_standin(small):
+    x, y, noise = small
+    with mock.patch.object(_hip, "mll_value_grad", ob.mll_value_grad):
+        lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise)
+        m = _model(x, y, lik)
+        h = syn.cfg_hypers(2, y)
+        m.initialize(**{"covar_module.mixture_means": h["mu"], "covar_module.mixture_scales": h["v"],
+                        "covar_module.mixture_weights": h["w"], "mean_module.constant": h["mean"]})
+        m.train(); lik.train()
+        mll = g.mlls.ExactMarginalLogLikelihood(lik, m)
+        assert isinstance(mll, g.mlls.marginal_log_likelihood.MarginalLogLikelihood)
+        loss = -mll(m(x), y)
+        assert loss.dim() == 0
+        loss.backward()
+        ref = orc.mll(x, y, h["mean"], noise, h["w"], h["mu"].reshape(4, 1), h["v"].reshape(4, 1))
+        assert abs(float(loss.detach()) + float(ref)) < 1e-12
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+        with pytest.raises(RuntimeError, match="train on the training inputs"):
+            m(x + 1.0)
+        res = train(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=12, miniter=2, stop=1e-9, lr=0.01,
+                    optim="AdamW", stopavg=3, progress=False)
+        assert set(res) >= {"loss", "delta_loss", "covar_module.raw_mixture_means", "raw_mixture_means"}
+        assert len(res["loss"]) == 12 and len(res["delta_loss"]) == 11 and res["loss"][-1] < res["loss"][0]
+        res2 = train(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=50, miniter=2, stop=1e3, lr=1e-6,
+                     optim="SGD", stopavg=3, progress=False)
+        assert len(res2["loss"]) == 4                          # early stop: first i > miniter with std(loss[-3:]) < stop
+    for bad in (dict(optim="LBFGS"), dict(lossfn="nope"), dict(optim="NUTS")):
+        with pytest.raises((ValueError, NotImplementedError)):
+            train(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=1, progress=False, **bad)
+
+
+def test_jitter_retry_policy_with_oracle_standin():
+    """psd_safe_cholesky semantics: retry with 1e-8, 1e-7, 1e-6 (fp64), warn each time, then NotPSDError."""
+    x = torch.linspace(0, 1, 12, dtype=D)
+    y = torch.zeros(12, dtype=D)
+    calls = []
+
+    def flaky(*a, **k):
+        jit = a[9] if len(a) > 9 else k.get("jitter", 0.0)
+        calls.append(jit)
+        out = ob.mll_value_grad(*a, **k)
+        if jit < 5e-8:
+            out["info"] = torch.ones_like(out["info"])
+        return out
+
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(torch.full((12,), 0.1, dtype=D))
+    m = _model(x, y, lik, Q=1)
+    m.train()
+    mll = g.mlls.ExactMarginalLogLikelihood(lik, m)
+    with mock.patch.object(_hip, "mll_value_grad", flaky), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        val = mll(m(x), y)
+    assert calls == [0.0, 1e-8, 1e-7] and torch.isfinite(val)
+    assert sum("added jitter" in str(w.message) for w in rec) == 2
+    always = lambda *a, **k: {**ob.mll_value_grad(*a, **k), "info": torch.tensor(3, dtype=torch.int32)}
+    with mock.patch.object(_hip, "mll_value_grad", always), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(g.utils.errors.NotPSDError):
+            mll(m(x), y)
+
+
+def test_fixed_noise_likelihood_semantics():
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lik = g.likelihoods.FixedNoiseGaussianLikelihood(torch.tensor([1e-9, 0.1], dtype=D))
+    assert any("Very small noise" in str(w.message) for w in rec) and float(lik.noise[0]) == 1e-6
+    lik2 = g.likelihoods.FixedNoiseGaussianLikelihood(torch.full((5,), 0.1), learn_additional_noise=True)
+    assert [n for n, _ in lik2.named_parameters()] == ["second_noise_covar.raw_noise"]
+    with pytest.raises(RuntimeError):
+        g.likelihoods.FixedNoiseGaussianLikelihood(torch.full((5,), 0.1)).second_noise = 0.1
+    with pytest.raises(RuntimeError):
+        g.models.ExactGP(torch.zeros(3), torch.zeros(3), likelihood=torch.nn.Identity())
