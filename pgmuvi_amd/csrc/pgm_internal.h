@@ -12,9 +12,9 @@ constexpr int PGM_MAX_D = 2;
 // batch share sizes; buffer b of a batch sits at base + b * stride.
 struct PgmDev {
   int n, np, nb, q, d, qd, dim_order, need_grad, batch;
-  int nslot, ntiles, pre_slots;
+  int nslot, ntiles, pre_slots, nitems;
   int64_t ld;                                   // == np
-  int64_t sA, sDinv, sPre, sVec, sPart, sLogdet;
+  int64_t sA, sDinv, sPre, sVec, sPart, sLogdet, sDpart;
   double* A;          // [batch][np*np]  upper blocks: K+noise -> U ; strictly lower blocks: V = U^-T
   double* Dinv;       // [batch][nb][2][NB*NB]  0: Uinv_kk ([p][m])   1: Uinv_kk^T = V_kk ([k][n])
   double* pre;        // [batch][3*qd + d][np]  cos, sin, x*v per (q,d); raw x per d
@@ -22,7 +22,9 @@ struct PgmDev {
   double* z;          // [batch][np]  U^-T r
   double* alpha;      // [batch][np]  A^-1 r
   double* logdet;     // [batch][nb]
-  double* partials;   // [batch][ntiles][nslot]
+  double* partials;   // [batch][nitems][nslot]
+  double* dpart;      // [batch][AINV_SPLITS][np]  partial column sums of squares of V
+  const int4* items;  // [nitems] (i, j, first k-block, k-blocks) of the inverse/gradient pass
   double* hyp;        // [batch][q + 2*q*d] copy of (w, mu, v) kept for prediction
   int* info;          // [batch]
   double jitter, noise_scalar;
@@ -38,13 +40,17 @@ struct pgm_ws {
   int64_t max_n, max_np;
   int max_q, max_d, max_batch, max_nb;
   size_t bytes;
-  double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp;
+  double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp, *dpart;
   int* info;
+  int4* items;           // device copy of the work-item table
+  std::vector<int4> items_host;
+  int items_nb, items_count, items_cap;
   // state of the last need_grad evaluation (for pgm_predict_f64)
   PgmDev last;
   bool last_valid;
   double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
   size_t pred_bytes;
+  int panel;             // block rows per delayed trailing update (k-depth = panel*128)
   // profiling
   bool prof_on;
   std::vector<hipEvent_t> ev_pool;

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   const int b = blockIdx.z;
   int ib, jb;
   tri_decode(blockIdx.x, ib, jb);
-  __shared__ double sm[2 * (3 * PGM_MAX_QD + PGM_MAX_D) * NB + PGM_MAX_QD];
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD doubles
   double* rowd = sm;
   double* cold = sm + P.pre_slots * NB;
   double* wl = cold + P.pre_slots * NB;
@@ -475,41 +475,51 @@ __global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
 }
 
 // ---------------------------------------------------------------------------
-// Step k trailing update (the dominant kernel):
-//   A_ij -= U_ki^T U_kj   k < i <= j           (Cholesky trailing update)
-//   R_ij -= U_ki^T V_kj   i > k >= j           (inverse factor, same sweep)
+// Trailing update with a panel of `dp` finished block rows k0..k0+dp-1 (the dominant
+// kernel), applied to block rows r_lo..r_hi-1:
+//   A_rj -= sum_p U_pr^T U_pj        r <= j            (Cholesky trailing update)
+//   R_rj -= sum_p U_pr^T V_pj        j <= k0+dp-1      (inverse factor, same sweep; p >= j)
+// Delaying the update until dp rows are finished multiplies the k-depth of every visit
+// of a C tile by dp, i.e. divides the read-modify-write traffic of the trailing matrix --
+// which, not MFMA issue, bounds a K=128 update on this machine.
+// The same kernel with dp=1 and a short row range is the in-panel update.
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256, 2) void k_update(PgmDev P, int k) {
+__global__ __launch_bounds__(256, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi) {
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
   constexpr int SUB = NB / C::BM;
   static_assert(C::BM == C::BN, "square tiles");
-  const int sub = blockIdx.x % (SUB * SUB), tile = blockIdx.x / (SUB * SUB);
+  // (An XCD-aware 8x8 super-block order was measured and rejected at this size: a whole
+  //  trailing update is only 1-2 co-resident sets of tiles, so the empty tiles of the
+  //  trapezoid unbalance the XCDs more than the L2 reuse returns.)
+  const int sub = blockIdx.x % (SUB * SUB);
+  int tile = blockIdx.x / (SUB * SUB);
   const int si = sub / SUB, sj = sub % SUB;
-  const int nrem = P.nb - 1 - k, nsyrk = nrem * (nrem + 1) / 2;
-  int i, j;
-  if (tile < nsyrk) {
-    tri_decode(tile, i, j);
-    i += k + 1; j += k + 1;
-  } else {
-    const int t2 = tile - nsyrk;
-    i = k + 1 + t2 / (k + 1);
-    j = t2 % (k + 1);
+  const int kend = k0 + dp - 1;
+  const int nR = P.need_grad ? kend + 1 : 0;              // inverse-factor tiles per block row
+  int r = r_lo;
+  for (; r < r_hi; ++r) {                                   // rows are few: linear decode
+    const int cnt = (P.nb - r) + nR;
+    if (tile < cnt) break;
+    tile -= cnt;
   }
+  const bool syrk = tile < P.nb - r;
+  const int j = syrk ? r + tile : tile - (P.nb - r);
+  const int pstart = (!syrk && j > k0) ? j : k0;            // V_pj vanishes for p < j
+  const bool assign = !syrk && j >= k0;                      // first contribution to this R tile
   double* A = P.A + b * P.sA;
+  const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
-  const double* pa0 = A + (int64_t)k * NB * ld + i * NB + si * C::BM;
-  const double* pb0;
-  int64_t ldb0;
-  if (j == k) { pb0 = P.Dinv + b * P.sDinv + ((int64_t)k * 2 + 1) * NB * NB + sj * C::BN; ldb0 = NB; }
-  else { pb0 = A + (int64_t)k * NB * ld + j * NB + sj * C::BN; ldb0 = ld; }
-  double* Cp = A + ((int64_t)i * NB + si * C::BM) * ld + j * NB + sj * C::BN;
+  double* Cp = A + ((int64_t)r * NB + si * C::BM) * ld + j * NB + sj * C::BN;
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   v4d acc[C::TM][C::TN];
-  if (j == k) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
-  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
-    pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
+  if (assign) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
+  gemm_tn<C>(lds, kend - pstart + 1, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    const int p = pstart + kb;
+    pa = A + (int64_t)p * NB * ld + r * NB + si * C::BM; lda = ld;
+    if (!syrk && p == j) { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + sj * C::BN; ldb = NB; }
+    else { pb = A + (int64_t)p * NB * ld + j * NB + sj * C::BN; ldb = ld; }
   }, acc);
   acc_store<C>(Cp, ld, acc, -1.0);
 }
@@ -533,16 +543,19 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   using C = CfgBig;
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
-  int i, j;
-  tri_decode(blockIdx.x, i, j);
+  // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
+  // that no single workgroup sets the makespan; the contraction below is linear in the tile
+  const int lb = blockIdx.x;
+  const int4 item = P.items[lb];
+  const int i = item.x, j = item.y, p0 = item.z, plen = item.w;
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   v4d acc[C::TM][C::TN];
   acc_zero<C>(acc);
-  gemm_tn<C>(lds, P.nb - j, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
-    const int p = j + kb;
+  gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    const int p = p0 + kb;
     if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB; lda = ld; }
     else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB; lda = NB; }
     if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB; ldb = ld; }
@@ -581,9 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
 
   const WavePos wp = wave_pos<C>();
   const double sym = (i == j) ? 1.0 : 2.0;
-  const double half_n = 0.5 / (double)P.n;
   double* mypart = wpart + wp.wave * P.nslot;
-  double gns = 0.0;
   // acc <- sym * G = sym * (alpha alpha^T - A^-1), in place; the diagonal of G is the noise gradient
 #pragma unroll
   for (int ti = 0; ti < C::TM; ++ti)
@@ -594,12 +605,8 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
         const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
         const int gi = i * NB + m, gj = j * NB + n;
         const bool valid = (gi < P.n) && (gj < P.n);
-        const double g = valid ? (arow[m] * acol[n] - acc[ti][tj][r]) : 0.0;
-        acc[ti][tj][r] = sym * g;
-        if (i == j && m == n && valid) {
-          gns += g;
-          if (P.g_noise) P.g_noise[(int64_t)b * P.n + gi] = half_n * g;
-        }
+        const double aa = (p0 == j) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
+        acc[ti][tj][r] = valid ? sym * (aa - acc[ti][tj][r]) : 0.0;
       }
 #pragma unroll 1
   for (int ti = 0; ti < C::TM; ++ti) {
@@ -700,12 +707,36 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
       }
     }
   }
-  gns = wave_sum(gns);
-  if (wp.lane == 0) mypart[P.nslot - 1] += gns;
   __syncthreads();
-  double* part = P.partials + b * P.sPart + (int64_t)blockIdx.x * P.nslot;
+  double* part = P.partials + b * P.sPart + (int64_t)lb * P.nslot;
   for (int s = threadIdx.x; s < P.nslot; s += NTHREADS)
     part[s] = wpart[s] + wpart[P.nslot + s] + wpart[2 * P.nslot + s] + wpart[3 * P.nslot + s];
+}
+
+// ---------------------------------------------------------------------------
+// diag(A^-1)_c = sum_k V[k][c]^2 (column sums of squares of the inverse factor), needed
+// for d mll / d noise_c = (alpha_c^2 - (A^-1)_cc) / 2N.  Memory-bound (reads V once).
+// grid (nb, AINV_SPLITS): column block x row split; partial sums reduced by k_finalize.
+// ---------------------------------------------------------------------------
+constexpr int AINV_SPLITS = 8;
+__global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
+  const int b = blockIdx.z, jb = blockIdx.x, sp = blockIdx.y;
+  if (P.info[b] != 0) return;
+  const double* A = P.A + b * P.sA;
+  const double* Vjj = P.Dinv + b * P.sDinv + ((int64_t)jb * 2 + 1) * NB * NB;
+  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int nrows = (P.nb - jb) * NB;                      // rows jb*NB .. np-1
+  const int per = (nrows / NB + AINV_SPLITS - 1) / AINV_SPLITS * NB;
+  const int r0 = sp * per, r1 = min(nrows, r0 + per);
+  double s = 0.0;
+  for (int rr = r0 + half; rr < r1; rr += 2) {
+    const double v = (rr < NB) ? Vjj[rr * NB + c] : A[(int64_t)(jb * NB + rr) * P.ld + jb * NB + c];
+    s += v * v;
+  }
+  __shared__ double red[NB];
+  if (half == 1) red[c] = s;
+  __syncthreads();
+  if (half == 0) P.dpart[b * P.sDpart + (int64_t)sp * P.np + jb * NB + c] = s + red[c];
 }
 
 // ---------------------------------------------------------------------------
@@ -734,7 +765,7 @@ __global__ __launch_bounds__(256) void k_finalize(PgmDev P) {
   for (int sidx = wave; sidx < P.nslot; sidx += NTHREADS / 64) {
     double acc = 0.0;
     const double* part = P.partials + b * P.sPart + sidx;
-    for (int tile = lane; tile < P.ntiles; tile += 64) acc += part[(int64_t)tile * P.nslot];
+    for (int tile = lane; tile < P.nitems; tile += 64) acc += part[(int64_t)tile * P.nslot];
     acc = wave_sum(acc);                       // fixed summation order: reproducible
     if (lane != 0) continue;
     if (sidx < Q) {
@@ -749,8 +780,16 @@ __global__ __launch_bounds__(256) void k_finalize(PgmDev P) {
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
   }
-  if (P.g_mean)
-    for (int i = t; i < P.n; i += NTHREADS) P.g_mean[(int64_t)b * P.n + i] = P.alpha[b * P.sVec + i] / (double)P.n;
+  for (int i = t; i < P.n; i += NTHREADS) {
+    const double al = P.alpha[b * P.sVec + i];
+    if (P.g_mean) P.g_mean[(int64_t)b * P.n + i] = al / (double)P.n;
+    if (P.g_noise) {
+      double dsum = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
+      P.g_noise[(int64_t)b * P.n + i] = half_n * (al * al - dsum);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -792,7 +831,7 @@ template <int D, int ORDER>
 __global__ __launch_bounds__(256) void k_pred_cross(PgmDev P, const double* __restrict__ xt, int64_t M, int64_t Mp,
                                                     double* __restrict__ Ks) {
   const int jb = blockIdx.x, ib = blockIdx.y;
-  __shared__ double sm[2 * (3 * PGM_MAX_QD + PGM_MAX_D) * NB + PGM_MAX_QD];
+  extern __shared__ __attribute__((aligned(16))) double sm[];
   double* rowd = sm;
   double* cold = sm + P.pre_slots * NB;
   double* wl = cold + P.pre_slots * NB;

@@ -1,0 +1,27 @@
+// evalloop.cpp -- runs a few N-point evaluations (for rocprofv3 timelines).  tools/evalloop [n] [reps] [need_grad]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include <vector>
+#include "../include/pgmuvi_hip.h"
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 5, ng = argc > 3 ? atoi(argv[3]) : 1, q = 4;
+  pgm_ws* ws; if (pgm_workspace_create(&ws, 0, n, q, 1, 1)) return 1;
+  std::vector<double> x(n), y(n), m(n, 0.0), nz(n, 0.01), w{0.5, 0.25, 0.1, 0.05}, mu{1 / 150., 1 / 67., 1 / 400., 1 / 31.}, v{1 / 1500., 1 / 670., 1 / 4000., 1 / 310.};
+  for (int i = 0; i < n; ++i) { x[i] = 3450.0 * i / n + 0.3 * sin(i); y[i] = sin(x[i] / 20) + 0.1 * cos(i * 0.7); }
+  auto dev = [](std::vector<double>& h) { double* p; hipMalloc((void**)&p, 8 * h.size()); hipMemcpy(p, h.data(), 8 * h.size(), hipMemcpyHostToDevice); return p; };
+  double *dx = dev(x), *dy = dev(y), *dm = dev(m), *dn = dev(nz), *dw = dev(w), *dmu = dev(mu), *dv = dev(v);
+  double* out; hipMalloc((void**)&out, 8 * (16 + 3 * n)); int* info; hipMalloc((void**)&info, 4);
+  hipStream_t st; hipStreamCreate(&st);
+  auto run = [&]() { pgm_mll_value_grad_f64(ws, dx, dy, dm, dn, 0, n, 1, dw, dmu, dv, q, 0, 0, ng, out, out + 1, out + 5, out + 9, out + 16, out + 16 + n, info, st); };
+  run(); hipStreamSynchronize(st);
+  auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; ++r) run();
+  hipStreamSynchronize(st);
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+  double h; hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
+  printf("n=%d need_grad=%d: %.3f ms/eval  mll=%.12f\n", n, ng, ms, h);
+  return 0;
+}
