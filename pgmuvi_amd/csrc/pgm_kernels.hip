@@ -318,13 +318,61 @@ __device__ __forceinline__ void diag_update(const DiagCtx& c, int s, int i, int 
   for (int r2 = 0; r2 < 4; ++r2) c.M[(i * DB + kq + 4 * r2) * PM + j * DB + n] = acc[r2];
 }
 
+// two independent trailing sub-blocks at once: their dependent MFMA chains interleave
+__device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, int j1, int i2, int j2, int lane) {
+  const int kq = lane >> 4, n = lane & 15;
+  v4d acc1, acc2;
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) {
+    acc1[r2] = (j1 == s) ? 0.0 : c.M[(i1 * DB + kq + 4 * r2) * PM + j1 * DB + n];
+    acc2[r2] = (j2 == s) ? 0.0 : c.M[(i2 * DB + kq + 4 * r2) * PM + j2 * DB + n];
+  }
+  double a1[4], b1[4], a2[4], b2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int krow = s * DB + 4 * r + kq;
+    a1[r] = -c.M[krow * PM + i1 * DB + n];
+    b1[r] = c.M[krow * PM + j1 * DB + n];
+    a2[r] = -c.M[krow * PM + i2 * DB + n];
+    b2[r] = c.M[krow * PM + j2 * DB + n];
+    if (j1 == s && n > 4 * r + kq) b1[r] = 0.0;
+    if (j2 == s && n > 4 * r + kq) b2[r] = 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[r], b1[r], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], b2[r], acc2, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) {
+    c.M[(i1 * DB + kq + 4 * r2) * PM + j1 * DB + n] = acc1[r2];
+    c.M[(i2 * DB + kq + 4 * r2) * PM + j2 * DB + n] = acc2[r2];
+  }
+}
+
 __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
   __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], red[8], dump[64], pbuf[4 * 32];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
+  __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
+  __shared__ int blkcnt[NB / DB];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
+  if (t < NB / DB) {                                           // thread s builds the list of step s
+    const int s = t, ns = NB / DB;
+    int cnt = 0;
+    for (int i = s + 1; i < ns; ++i) {
+      for (int j = 0; j <= s; ++j) blklist[s * BLK_MAX + cnt++] = (unsigned char)((i << 4) | j);
+      for (int j = i; j < ns; ++j) {
+        if (i == s + 1 && j == s + 1) continue;                // the next diagonal sub-block belongs to wave 0
+        blklist[s * BLK_MAX + cnt++] = (unsigned char)((i << 4) | j);
+      }
+    }
+    blkcnt[s] = cnt;
+  }
   DiagCtx c;
   c.M = M; c.uiS = uiS; c.udg = udg; c.dump = dump; c.pbuf = pbuf;
   c.Akk = P.A + b * P.sA + (int64_t)k * NB * P.ld + k * NB;
@@ -353,21 +401,22 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
   for (int s = 0; s < NS; ++s) {
     lds_barrier();
     STAMP();
+#ifdef PGM_DIAG_STAMPS
+    const long long wb0_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- (b) block row s
     if (wave < NS - 1) {
       const int j = (wave < s) ? wave : wave + 1;
       diag_rowsolve(c, s, j, lane);
-    } else {
-      if (lane < DB) {
-        double acc = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
-        zsv[s * DB + lane] = acc;
-      }
-      diag_store_diagblock(c, s, lane);
     }
+#ifdef PGM_DIAG_STAMPS
+    const long long wb1_ = __builtin_amdgcn_s_memtime();
+#endif
     lds_barrier();
     STAMP();
+#ifdef PGM_DIAG_STAMPS
+    const long long wc0_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- (c) trailing sub-blocks; wave 0 runs ahead on the next diagonal sub-block
     if (wave == 0) {
       if (s + 1 < NS) {
@@ -378,7 +427,16 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
       }
     } else {
       if (wave == NS - 1) {
-        // forward substitution / alpha ride along: 2 columns per lane
+        // bookkeeping wave: z_s = V_ss r_s, results of the diagonal sub-block to global memory,
+        // then the forward substitution / alpha updates with block row s (2 columns per lane)
+        if (lane < DB) {
+          double acc = 0.0;
+#pragma unroll
+          for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
+          zsv[s * DB + lane] = acc;
+        }
+        diag_store_diagblock(c, s, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int colg = lane + 64 * u, jb = colg / DB;
@@ -392,22 +450,27 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
           if (jb > s) rsv[colg] -= acc; else alv[colg] += acc;
         }
       }
-      const int nrem = NS - 1 - s;
-      const int nT = nrem * (nrem + 1) / 2, nR = nrem * (s + 1);
-      for (int idx = wave - 1; idx < nT + nR; idx += NS - 1) {
-        int i, j;
-        if (idx < nT) {
-          tri_decode(idx, i, j);
-          i += s + 1; j += s + 1;
-          if (i == s + 1 && j == s + 1) continue;       // done by wave 0
-        } else {
-          const int t2 = idx - nT;
-          i = s + 1 + t2 / (s + 1);
-          j = t2 % (s + 1);
+      // trailing sub-blocks of step s from the precomputed list (instruction issue, not MFMA, is
+      // what this kernel runs out of: no per-block decoding here), dealt over the worker waves
+      // 1..6 (wave 7 keeps the books) and processed two at a time so that the dependent MFMA
+      // chains of a pair interleave
+      const int nblk = blkcnt[s];
+      const unsigned char* bl = blklist + s * BLK_MAX;
+      if (wave < NS - 1) {
+        for (int idx = wave - 1; idx < nblk; idx += 2 * (NS - 2)) {
+          const int e1 = __builtin_amdgcn_readfirstlane((int)bl[idx]);
+          if (idx + (NS - 2) < nblk) {
+            const int e2 = __builtin_amdgcn_readfirstlane((int)bl[idx + (NS - 2)]);
+            diag_update2(c, s, e1 >> 4, e1 & 15, e2 >> 4, e2 & 15, lane);
+          } else {
+            diag_update(c, s, e1 >> 4, e1 & 15, lane);
+          }
         }
-        diag_update(c, s, i, j, lane);
       }
     }
+#ifdef PGM_DIAG_STAMPS
+    if (lane == 0 && k == 0 && s < 4) { P.partials[64 + wave * 16 + s * 2] = (double)(wb1_ - wb0_); P.partials[64 + wave * 16 + s * 2 + 1] = (double)(__builtin_amdgcn_s_memtime() - wc0_); }
+#endif
   }
   __syncthreads();
   if (t < NB) {
