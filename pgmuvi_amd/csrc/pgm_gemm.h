@@ -24,9 +24,14 @@ constexpr int NB = 128;   // block size of the blocked algorithms (rows per k-bl
 constexpr int KB = 16;    // k rows staged per LDS chunk
 constexpr int NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  // chunks kept in flight in registers ahead of the one being multiplied: a wave of a small tile
+  // issues only 16 MFMAs (~0.4 us) per chunk, less than one L2/Infinity-Cache round trip, so a single
+  // prefetched chunk leaves the loop latency-bound; PF > 1 hides it
+  static constexpr int PF = PF_;
+  static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8, "prefetch depth must divide 8 chunks per k-block");
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
@@ -67,62 +72,68 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
   const int t = threadIdx.x;
   const WavePos wp = wave_pos<C>();
   const int nchunks = nkb * (NB / KB);
-  v2d ra[C::VA], rb[C::VB];
+  constexpr int D = C::PF;
+  v2d ra[D][C::VA], rb[D][C::VB];
 
-  auto gload = [&](int c) {
+  auto gload = [&](int c, v2d (&xa)[C::VA], v2d (&xb)[C::VB]) {
     const int kb = c / (NB / KB), kr = (c % (NB / KB)) * KB;
     const double* pa; const double* pb; int64_t lda, ldb;
     ptrs(kb, pa, lda, pb, ldb);
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
       const int e = t + NTHREADS * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
-      ra[s] = *reinterpret_cast<const v2d*>(pa + (int64_t)(kr + row) * lda + 2 * c2);
+      xa[s] = *reinterpret_cast<const v2d*>(pa + (int64_t)(kr + row) * lda + 2 * c2);
     }
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
       const int e = t + NTHREADS * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
-      rb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
+      xb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const v2d (&xa)[C::VA], const v2d (&xb)[C::VB]) {
     double* As = lds + buf * C::STAGE;
     double* Bs = As + KB * C::PA;
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
       const int e = t + NTHREADS * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
-      *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = ra[s];
+      *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = xa[s];
     }
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
       const int e = t + NTHREADS * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
-      *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = rb[s];
+      *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = xb[s];
     }
   };
 
-  gload(0);
-  sstore(0);
+  // register set u holds chunk c with c % D == u; LDS is double-buffered
+#pragma unroll
+  for (int u = 0; u < D; ++u) gload(u, ra[u], rb[u]);       // nchunks >= 8 >= D
+  sstore(0, ra[0], rb[0]);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = (c + 1 < nchunks);
-    if (more) gload(c + 1);
-    const double* As = lds + (c & 1) * C::STAGE;
-    const double* Bs = As + KB * C::PA;
+  for (int c0 = 0; c0 < nchunks; c0 += D) {
 #pragma unroll
-    for (int kk = 0; kk < KB / 4; ++kk) {
-      const int krow = kk * 4 + (wp.lane >> 4);
-      double a[C::TM], b[C::TN];
+    for (int u = 0; u < D; ++u) {
+      const int c = c0 + u;
+      if (c + D < nchunks) gload(c + D, ra[u], rb[u]);       // set u is free: chunk c already sits in LDS
+      const double* As = lds + (c & 1) * C::STAGE;
+      const double* Bs = As + KB * C::PA;
 #pragma unroll
-      for (int ti = 0; ti < C::TM; ++ti) a[ti] = As[krow * C::PA + wp.m0 + ti * 16 + (wp.lane & 15)];
+      for (int kk = 0; kk < KB / 4; ++kk) {
+        const int krow = kk * 4 + (wp.lane >> 4);
+        double a[C::TM], b[C::TN];
 #pragma unroll
-      for (int tj = 0; tj < C::TN; ++tj) b[tj] = Bs[krow * C::PB + wp.n0 + tj * 16 + (wp.lane & 15)];
+        for (int ti = 0; ti < C::TM; ++ti) a[ti] = As[krow * C::PA + wp.m0 + ti * 16 + (wp.lane & 15)];
 #pragma unroll
-      for (int ti = 0; ti < C::TM; ++ti)
+        for (int tj = 0; tj < C::TN; ++tj) b[tj] = Bs[krow * C::PB + wp.n0 + tj * 16 + (wp.lane & 15)];
 #pragma unroll
-        for (int tj = 0; tj < C::TN; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < C::TN; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      }
+      if (c + 1 < nchunks) sstore((c + 1) & 1, ra[(u + 1) % D], rb[(u + 1) % D]);
+      __syncthreads();
     }
-    if (more) sstore((c + 1) & 1);
-    __syncthreads();
   }
 }
 

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
 // Epilogue: the forward substitution rides along,  r_j -= U_kj^T z_k  (j > k), and
 // so does alpha,  alpha_j += V_kj^T z_k  (j < k).
 // ---------------------------------------------------------------------------
-using CfgTrsm = TileCfg<128, 32, 32, 32>;
+using CfgTrsm = TileCfg<128, 32, 32, 32, 4>;
 __global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
   using C = CfgTrsm;
   const int b = blockIdx.z;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_update(PgmDev P, int k0, int dp, int
 // parameter and tile (summed in fixed order by k_finalize: bitwise reproducible).
 // ---------------------------------------------------------------------------
 using CfgBig = TileCfg<128, 128, 64, 64>;
-using CfgSmall = TileCfg<64, 64, 32, 32>;
+using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
 constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);          // alpha slices, weights, wave partials
