@@ -212,7 +212,9 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane) 
     va[r] = (g + 4 * r == n) ? 1.0 : 0.0;
   }
   double fa[4], fb[4];
-  int failp = -1;
+  // No test inside the pivot chain: a non-positive pivot turns into NaN (rsq of a negative) or
+  // inf and poisons everything after it; the first bad diagonal entry is located once, after
+  // the block is finished (k_diag tail), which keeps ~5 instructions per pivot off the chain.
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     pbuf[g * 32 + n] = ua[m];
@@ -224,10 +226,7 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
-      double dp = readlane_d(pa[pl], 4 * m + pl);
-      const bool bad = !(dp > 0.0);
-      failp = (bad && failp < 0) ? (4 * m + pl) : failp;
-      dp = bad ? 1.0 : dp;
+      const double dp = readlane_d(pa[pl], 4 * m + pl);
       const double rs = rsqrt_nr(dp);
       pa[pl] *= rs;
       pb[pl] *= rs;
@@ -256,7 +255,6 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane) 
     double* dst = (n == i) ? (c.udg + s * DB + i) : mydump;
     *dst = fa[r];                                  // U_ii = sqrt(pivot)
   }
-  if (failp >= 0 && lane == 0 && *c.info == 0) *c.info = c.kbase + s * DB + failp + 1;
 }
 
 // results of sub-block s that live on the diagonal: u (strictly upper + sqrt of the
@@ -476,6 +474,12 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
   if (t < NB) {
     P.z[b * P.sVec + k * NB + t] = zsv[t];
     P.alpha[b * P.sVec + k * NB + t] = alv[t];
+  }
+  // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
+  if (t < 64) {
+    const bool bad0 = !(udg[t] > 0.0 && udg[t] < 1e300), bad1 = !(udg[t + 64] > 0.0 && udg[t + 64] < 1e300);
+    const unsigned long long m0 = __ballot(bad0), m1 = __ballot(bad1);
+    if (t == 0 && (m0 | m1) && *c.info == 0) *c.info = c.kbase + 1 + (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
   }
   double lg = (t < NB) ? 2.0 * log(udg[t]) : 0.0;
   lg = wave_sum(lg);
@@ -993,6 +997,25 @@ __global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
   if (s == 12345.678) out[0] = s;
+}
+
+// GEMM-core efficiency probe (tools only): every workgroup multiplies `nkb` k-blocks of operand
+// strips; `spread` strips apart so that the operands either stay in L2 (spread = 0) or stream
+template <class C>
+__global__ __launch_bounds__(256, 2) void k_gemm_probe(const double* A, int64_t ld, int nkb, int spread, double* out) {
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  const int64_t off = (int64_t)(blockIdx.x % 16) * spread * C::BM;
+  gemm_tn<C>(lds, nkb, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = A + (int64_t)kb * NB * ld + off; lda = ld; pb = A + (int64_t)kb * NB * ld + off + C::BM; ldb = ld;
+  }, acc);
+  double s = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) s += acc[ti][tj][0] + acc[ti][tj][3];
+  if (s == 1.2345) out[0] = s;
 }
 
 }  // namespace

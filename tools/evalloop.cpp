@@ -7,9 +7,10 @@
 #include <vector>
 #include "../include/pgmuvi_hip.h"
 int main(int argc, char** argv) {
-  const int n = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 5, ng = argc > 3 ? atoi(argv[3]) : 1, q = 4;
+  const int n = argc > 1 ? atoi(argv[1]) : 4096, reps = argc > 2 ? atoi(argv[2]) : 5, ng = argc > 3 ? atoi(argv[3]) : 1, q = argc > 4 ? atoi(argv[4]) : 4;
   pgm_ws* ws; if (pgm_workspace_create(&ws, 0, n, q, 1, 1)) return 1;
-  std::vector<double> x(n), y(n), m(n, 0.0), nz(n, 0.01), w{0.5, 0.25, 0.1, 0.05}, mu{1 / 150., 1 / 67., 1 / 400., 1 / 31.}, v{1 / 1500., 1 / 670., 1 / 4000., 1 / 310.};
+  std::vector<double> x(n), y(n), m(n, 0.0), nz(n, 0.01), w(q), mu(q), v(q);
+  for (int a = 0; a < q; ++a) { w[a] = 0.5 / (a + 1); mu[a] = 1.0 / (150.0 - 13.0 * a); v[a] = mu[a] / 10.0; }
   for (int i = 0; i < n; ++i) { x[i] = 3450.0 * i / n + 0.3 * sin(i); y[i] = sin(x[i] / 20) + 0.1 * cos(i * 0.7); }
   auto dev = [](std::vector<double>& h) { double* p; hipMalloc((void**)&p, 8 * h.size()); hipMemcpy(p, h.data(), 8 * h.size(), hipMemcpyHostToDevice); return p; };
   double *dx = dev(x), *dy = dev(y), *dm = dev(m), *dn = dev(nz), *dw = dev(w), *dmu = dev(mu), *dv = dev(v);
