@@ -146,9 +146,20 @@ def main():
     upd_ms, upd_launches = prof["trailing_update"]
     flops = update_flops(n) * B * args.steps
     achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    # HBM-side bytes per launch of this kernel: not measurable from inside the process; taken from the
+    # committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 for gfx950)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if n == 4096 and B == 1 and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        rows = [v for k, v in pmc.items() if k.startswith("k_update")]
+        tot_l = sum(r["launches"] for r in rows)
+        if tot_l:
+            traffic = sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot_l
+            traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, same workload, earlier run)"
     roofline = dict(bound="mfma", kernel="trailing_update (k_update: v_mfma_f64_16x16x4_f64 TN tile GEMM)",
                     achieved=round(achieved, 3), peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                     avg_launch_us=round(upd_ms / max(upd_launches, 1) * 1e3, 2), launches_per_eval=upd_launches // args.steps,
                     flops_per_eval=update_flops(n) * B)
     phases = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
