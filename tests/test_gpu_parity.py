@@ -334,3 +334,63 @@ def test_cpu_tensors_are_refused(dev):
     x = torch.linspace(0, 1, 8, dtype=D)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _hip.mll_value_grad(x, x, x, x, None, torch.ones(1, dtype=D), torch.ones(1, 1, dtype=D), torch.ones(1, 1, dtype=D))
+
+
+def test_config4_shape_2d_8_bands(dev):
+    """Config 4 (2-D multiwavelength, 8 bands): 8 x 256 points against the oracle, and the
+    full 8 x 1024 = 8192-point problem through size-independent properties."""
+    x, y, e = syn.cfg4(n_per_band=256)
+    xd, yd, nz = x.double(), y.double(), e.double() ** 2
+    h = syn.cfg_hypers(4, yd)
+    w, mu, v = h["w"], h["mu"].reshape(3, 2), h["v"].reshape(3, 2)
+    for order in (0, 1):
+        val, gr = orc.mll_value_grad_closed_form(xd, yd, h["mean"], nz, w, mu, v, order)
+        out = _hip_eval(dev, xd, yd, h["mean"], nz, w, mu, v, order)
+        assert int(out["info"]) == 0 and abs(float(out["mll"]) - float(val)) < MLL_TOL
+        for p in ("w", "mu", "v", "noise", "mean"):
+            assert _rel(out[f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, (p, order)
+    x, y, e = syn.cfg4()                                   # N = 8192, d = 2, Q = 3
+    xd, yd, nz = x.double(), y.double(), e.double() ** 2
+    assert xd.shape == (8192, 2)
+    h = syn.cfg_hypers(4, yd)
+    base = _hip_eval(dev, xd, yd, h["mean"], nz, w, mu, v)
+    assert int(base["info"]) == 0 and math.isfinite(float(base["mll"]))
+    perm = torch.randperm(8192, generator=torch.Generator().manual_seed(4))
+    pout = _hip_eval(dev, xd[perm], yd[perm], h["mean"], nz[perm], w, mu, v)
+    assert abs(float(base["mll"]) - float(pout["mll"])) < 1e-9
+    for p in ("w", "mu", "v"):
+        assert _rel(pout[f"g_{p}"], base[f"g_{p}"]) < 1e-7
+    assert _rel(pout["g_noise"], base["g_noise"][perm.to(dev)]) < 1e-7
+    v0 = _hip_eval(dev, xd, yd, h["mean"], nz, w, mu, v, need_grad=False)
+    assert float(v0["mll"]) == float(base["mll"])
+    # directional derivative along the gradient of (w, mu, v) against central differences of the value
+    g = {p: base[f"g_{p}"].cpu() for p in ("w", "mu", "v")}
+    gn = math.sqrt(sum(float((t ** 2).sum()) for t in g.values()))
+    eps = 1e-6 / gn
+    plus = _hip_eval(dev, xd, yd, h["mean"], nz, w + eps * g["w"], mu + eps * g["mu"], v + eps * g["v"], need_grad=False)
+    minus = _hip_eval(dev, xd, yd, h["mean"], nz, w - eps * g["w"], mu - eps * g["mu"], v - eps * g["v"], need_grad=False)
+    fd = (float(plus["mll"]) - float(minus["mll"])) / (2 * eps)
+    assert abs(fd - gn * gn) < 1e-4 * gn * gn
+
+
+def test_config3_shape_batch_of_2048_point_curves(dev):
+    """Config 3 shape: a shard of N=2048, Q=4 light curves evaluated together; first and last
+    against the oracle, all of them finite and mutually independent of batch position."""
+    B, n = 6, 2048
+    xs, ys, ns, ws, mus, vs, means = [], [], [], [], [], [], []
+    for i in range(B):
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=n)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        xs.append(t.double().reshape(n, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+        ws.append(h["w"]); mus.append(h["mu"].reshape(4, 1)); vs.append(h["v"].reshape(4, 1)); means.append(h["mean"].expand(n))
+    st = lambda L: torch.stack(L).to(dev)
+    out = evaluate_batch(st(xs), st(ys), st(means), st(ns), st(ws), st(mus), st(vs))
+    rev = evaluate_batch(st(xs[::-1]), st(ys[::-1]), st(means[::-1]), st(ns[::-1]), st(ws[::-1]), st(mus[::-1]), st(vs[::-1]))
+    torch.cuda.synchronize()
+    assert int(out["info"].abs().max()) == 0 and bool(torch.isfinite(out["mll"]).all())
+    assert torch.equal(out["mll"], rev["mll"].flip(0)) and torch.equal(out["g_mu"], rev["g_mu"].flip(0))
+    for i in (0, B - 1):
+        val, gr = orc.mll_value_grad_closed_form(xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
+        assert abs(float(val) - float(out["mll"][i])) < MLL_TOL
+        for p in ("w", "mu", "v"):
+            assert _rel(out[f"g_{p}"][i].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL
