@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
 // ---------------------------------------------------------------------------
 constexpr int DB = 16;
 constexpr int PM = NB + 16;
-constexpr int DIAG_THREADS = 512;
+constexpr int DIAG_THREADS = 1024;        // 16 wavefronts: the chain wave, 14 workers, one bookkeeper
+constexpr int DIAG_WAVES = DIAG_THREADS / 64;
 
 __device__ __forceinline__ double readlane_d(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -257,25 +258,10 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane) 
   }
 }
 
-// results of sub-block s that live on the diagonal: u (strictly upper + sqrt of the
-// pivots) to the matrix, V_ss to both inverse images; one wavefront, 4 elements per lane
-__device__ __forceinline__ void diag_store_diagblock(const DiagCtx& c, int s, int lane) {
-  const int kq = lane >> 4, n = lane & 15;
-#pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) {
-    const int i = kq + 4 * r2;
-    const double v = c.M[(s * DB + i) * PM + s * DB + n];
-    const int gi = s * DB + i, gj = s * DB + n;
-    if (n > i) c.Akk[(int64_t)gi * c.ld + gj] = v;
-    else {
-      if (n == i) c.Akk[(int64_t)gi * c.ld + gj] = c.udg[gi];
-      c.Dinv1[gi * NB + gj] = v;
-      c.Dinv0[gj * NB + gi] = v;
-    }
-  }
-}
-
-// (b) X(s,j) <- V_ss X(s,j), in place; finished rows go straight to global memory
+// (b) X(s,j) <- V_ss X(s,j), in place.  Finished V blocks leave for global memory at once, from
+// the wave that made them: a CU retires only ~10 B/clk of stores, so the 130 KB of inverse images
+// must trickle out beside the arithmetic.  U_kk itself is never read again (later steps use U_kj,
+// j > k, and the inverse images) and is not written back.
 __device__ __forceinline__ void diag_rowsolve(const DiagCtx& c, int s, int j, int lane) {
   const int kq = lane >> 4, n = lane & 15;
   double b[4];
@@ -289,12 +275,25 @@ __device__ __forceinline__ void diag_rowsolve(const DiagCtx& c, int s, int j, in
   for (int r2 = 0; r2 < 4; ++r2) {
     const int row = s * DB + kq + 4 * r2, colg = j * DB + n;
     c.M[row * PM + colg] = acc[r2];
-    if (j > s) {
-      c.Akk[(int64_t)row * c.ld + colg] = acc[r2];       // U_kk block (s,j)
-    } else {
-      c.Dinv1[row * NB + colg] = acc[r2];                // V row-major
-      c.Dinv0[colg * NB + row] = acc[r2];                // and transposed (Uinv)
-    }
+  }
+}
+
+// block (s, j), j <= s, of V = U^-T is final: write it to both inverse images.  Called by worker
+// waves AFTER their trailing sub-blocks of the step, so that the (slow: a CU retires ~10 B/clk)
+// stores overlap the chain wave's next factorisation instead of sitting in front of a barrier.
+__device__ __forceinline__ void diag_store_vblock(const DiagCtx& c, int s, int j, int lane) {
+  const int kq = lane >> 4, n = lane & 15;
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) {                       // row-major image: lanes along the columns
+    const int i = kq + 4 * r2;
+    const double v = c.M[(s * DB + i) * PM + j * DB + n];
+    if (j < s || n <= i) c.Dinv1[(s * DB + i) * NB + j * DB + n] = v;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {                          // transposed image: lanes along the rows
+    const int col = 4 * u + kq, i = n;
+    const double v = c.M[(s * DB + i) * PM + j * DB + col];
+    if (j < s || col <= i) c.Dinv0[(j * DB + col) * NB + s * DB + i] = v;
   }
 }
 
@@ -348,12 +347,12 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
   }
 }
 
-__global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
+__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k) {
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
-  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], red[8], dump[64], pbuf[4 * 32];
+  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], red[DIAG_WAVES], dump[64], pbuf[4 * 32];
   constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
   __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
   __shared__ int blkcnt[NB / DB];
@@ -393,6 +392,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
 #define STAMP() do {} while (0)
 #endif
   STAMP();
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);              // the chain wave wins issue arbitration on its SIMD
   if (wave == 0) diag_potrf16(c, 0, lane);
   STAMP();
   constexpr int NS = NB / DB;
@@ -406,6 +406,13 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
     if (wave < NS - 1) {
       const int j = (wave < s) ? wave : wave + 1;
       diag_rowsolve(c, s, j, lane);
+    } else if (wave == NS - 1) {                     // z_s = V_ss r_s (r_s is final since step s-1)
+      if (lane < DB) {
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
+        zsv[s * DB + lane] = acc;
+      }
     }
 #ifdef PGM_DIAG_STAMPS
     const long long wb1_ = __builtin_amdgcn_s_memtime();
@@ -424,17 +431,8 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
         STAMP();
       }
     } else {
-      if (wave == NS - 1) {
-        // bookkeeping wave: z_s = V_ss r_s, results of the diagonal sub-block to global memory,
-        // then the forward substitution / alpha updates with block row s (2 columns per lane)
-        if (lane < DB) {
-          double acc = 0.0;
-#pragma unroll
-          for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
-          zsv[s * DB + lane] = acc;
-        }
-        diag_store_diagblock(c, s, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (wave == DIAG_WAVES - 1) {
+        // bookkeeping wave: forward substitution / alpha updates with block row s (2 columns per lane)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int colg = lane + 64 * u, jb = colg / DB;
@@ -450,20 +448,22 @@ __global__ __launch_bounds__(DIAG_THREADS, 2) void k_diag(PgmDev P, int k) {
       }
       // trailing sub-blocks of step s from the precomputed list (instruction issue, not MFMA, is
       // what this kernel runs out of: no per-block decoding here), dealt over the worker waves
-      // 1..6 (wave 7 keeps the books) and processed two at a time so that the dependent MFMA
+      // 1..14 (the last wave keeps the books) and processed two at a time so that the dependent MFMA
       // chains of a pair interleave
       const int nblk = blkcnt[s];
       const unsigned char* bl = blklist + s * BLK_MAX;
-      if (wave < NS - 1) {
-        for (int idx = wave - 1; idx < nblk; idx += 2 * (NS - 2)) {
+      constexpr int NWORK = DIAG_WAVES - 2;
+      if (wave < DIAG_WAVES - 1) {
+        for (int idx = wave - 1; idx < nblk; idx += 2 * NWORK) {
           const int e1 = __builtin_amdgcn_readfirstlane((int)bl[idx]);
-          if (idx + (NS - 2) < nblk) {
-            const int e2 = __builtin_amdgcn_readfirstlane((int)bl[idx + (NS - 2)]);
+          if (idx + NWORK < nblk) {
+            const int e2 = __builtin_amdgcn_readfirstlane((int)bl[idx + NWORK]);
             diag_update2(c, s, e1 >> 4, e1 & 15, e2 >> 4, e2 & 15, lane);
           } else {
             diag_update(c, s, e1 >> 4, e1 & 15, lane);
           }
         }
+        if (wave - 1 <= s && wave - 1 < NS) diag_store_vblock(c, s, wave - 1, lane);
       }
     }
 #ifdef PGM_DIAG_STAMPS
