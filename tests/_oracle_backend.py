@@ -46,3 +46,34 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     out = {k: t.to(y.device) for k, t in out.items()}
     out["workspace"] = None
     return out
+
+
+class _Remember:
+    """What the last stand-in evaluation was called with (for the predict stand-in)."""
+    last = None
+
+
+_orig_mll_value_grad = mll_value_grad
+
+
+def mll_value_grad_remember(*a, **k):
+    _Remember.last = (a, k)
+    return _orig_mll_value_grad(*a, **k)
+
+
+def predict(ws, x_test, mean_test):
+    """TEST-ONLY stand-in for ``pgmuvi_amd._hip.predict`` (posterior by the oracle)."""
+    (x, y, mean, noise, noise_scalar, w, mu, v, dim_order, *_), _k = _Remember.last
+    D = torch.float64
+    n = y.shape[-1]
+    nv = torch.zeros(n, dtype=D) if noise is None else noise.detach().to(D).reshape(n)
+    if noise_scalar is not None:
+        nv = nv + torch.as_tensor(noise_scalar).detach().to(D)
+    q = w.shape[-1]
+    xd = x.detach().to(D).reshape(n, -1)
+    d = xd.shape[-1]
+    xs = x_test.detach().to(D).reshape(x_test.shape[0], -1)
+    pm, pv = orc.posterior(xd, y.detach().to(D), mean.detach().to(D).expand(n), nv, w.detach().to(D).reshape(q),
+                           mu.detach().to(D).reshape(q, d), v.detach().to(D).reshape(q, d), xs,
+                           mean_test.detach().to(D).expand(xs.shape[0]), dim_order)
+    return pm, pv

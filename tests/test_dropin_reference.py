@@ -82,3 +82,28 @@ def test_reference_lightcurve_fit_2d_and_learned_noise():
         print("FIT2D_OK")
     """)
     assert "FIT2D_OK" in out
+
+
+def test_reference_eval_mode_prediction_path():
+    """The calls ``Lightcurve.plot()/_plot_1d`` make after a fit (lightcurve.py:9607-9631, 9862-9868):
+    eval mode, ``likelihood(model(x_fine))``, ``confidence_region()``."""
+    out = _run("""
+        import gpytorch
+        from pgmuvi.lightcurve import Lightcurve
+        t, y, e = syn.cfg2(n_obs=60)
+        with mock.patch.object(_hip, "mll_value_grad", ob.mll_value_grad_remember), mock.patch.object(_hip, "predict", ob.predict):
+            lc = Lightcurve(t.double(), y.double(), yerr=e.double(), max_samples=None).double()
+            lc.fit(model="1D", num_mixtures=2, periods=[150.0, 67.0], training_iter=3, lr=0.01, stop=None, miniter=1)
+            with torch.no_grad(), gpytorch.settings.fast_pred_var():
+                lc._eval()
+                x_fine = torch.linspace(float(t.min()), float(t.max()), 200, dtype=torch.float64)
+                pred = lc.likelihood(lc.model(x_fine))
+                lower, upper = pred.confidence_region()
+        assert pred.mean.shape == (200,) and torch.isfinite(pred.mean).all()
+        assert torch.all(upper >= lower) and torch.all(pred.variance >= -1e-9)
+        # the posterior mean passes close to the data where the noise is small
+        resid = (torch.as_tensor(np.interp(t.numpy(), x_fine.numpy(), pred.mean.numpy())) - y).abs()
+        assert float(resid.median()) < 0.5
+        print("EVAL_OK")
+    """)
+    assert "EVAL_OK" in out
