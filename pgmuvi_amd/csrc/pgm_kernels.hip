@@ -17,6 +17,32 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// exp(x) for x <= 0 in fp64, ~1 ulp: n = rint(x log2 e), r = x - n ln 2 (two-part), degree-13 Taylor
+// polynomial on |r| <= ln2/2 (truncation 4e-18), scaled by 2^n with v_ldexp_f64 (underflows to 0
+// by itself).  19 instructions against ~35 for the library call; every N^2 pass pays one per
+// (pair, mixture, dimension).
+__device__ __forceinline__ double exp_neg(double x) {
+  x = fmax(x, -800.0);                                    // 2^-1154: ldexp flushes to 0, n stays an int
+  const double n = rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                      // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);          // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);         // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);         // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);        // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);          // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);         // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);         // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);         // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);        // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);        // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
 // idx -> (i <= j) of the column-major enumeration of an upper triangle
 __device__ __forceinline__ void tri_decode(int idx, int& i, int& j) {
   int jj = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
@@ -88,7 +114,7 @@ __device__ __forceinline__ double sm_pair(const double* rowd, const double* cold
     for (int dd = 0; dd < D; ++dd) {
       const int qd = q * D + dd;
       const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-      const double e = exp(-TWO_PI_SQ * ds * ds);
+      const double e = exp_neg(-TWO_PI_SQ * ds * ds);
       const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
                         rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
       if (ORDER == 0) S[dd] += wl[q] * e * cc; else prod *= e * cc;
@@ -705,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
               for (int r = 0; r < 4; ++r) {
                 const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
                 const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-                const double e = exp(-TWO_PI_SQ * ds * ds);
+                const double e = exp_neg(-TWO_PI_SQ * ds * ds);
                 const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
                                   rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
                 Sd[dd][tj][r] += wl[q0 + ql] * e * cc;
@@ -736,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
               const double rc = rowd[(qd * 3 + 0) * NB + m], rsn = rowd[(qd * 3 + 1) * NB + m];
               const double cc_ = cold[(qd * 3 + 0) * NB + n], cs_ = cold[(qd * 3 + 1) * NB + n];
               const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-              E[dd] = exp(-TWO_PI_SQ * ds * ds);
+              E[dd] = exp_neg(-TWO_PI_SQ * ds * ds);
               CC[dd] = rc * cc_ + rsn * cs_;
               SN[dd] = rsn * cc_ - rc * cs_;
               TAU[dd] = rowx[dd * NB + m] - colx[dd * NB + n];
@@ -785,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
 // for d mll / d noise_c = (alpha_c^2 - (A^-1)_cc) / 2N.  Memory-bound (reads V once).
 // grid (nb, AINV_SPLITS): column block x row split; partial sums reduced by k_finalize.
 // ---------------------------------------------------------------------------
-constexpr int AINV_SPLITS = 8;
+constexpr int AINV_SPLITS = 32;
 __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
   const int b = blockIdx.z, jb = blockIdx.x, sp = blockIdx.y;
   if (P.info[b] != 0) return;
@@ -793,13 +819,19 @@ __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
   const double* Vjj = P.Dinv + b * P.sDinv + ((int64_t)jb * 2 + 1) * NB * NB;
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
   const int nrows = (P.nb - jb) * NB;                      // rows jb*NB .. np-1
-  const int per = (nrows / NB + AINV_SPLITS - 1) / AINV_SPLITS * NB;
+  const int per = ((nrows + AINV_SPLITS - 1) / AINV_SPLITS + 7) / 8 * 8;
   const int r0 = sp * per, r1 = min(nrows, r0 + per);
-  double s = 0.0;
-  for (int rr = r0 + half; rr < r1; rr += 2) {
-    const double v = (rr < NB) ? Vjj[rr * NB + c] : A[(int64_t)(jb * NB + rr) * P.ld + jb * NB + c];
-    s += v * v;
+  auto ld = [&](int rr) -> double {
+    return (rr < NB) ? Vjj[rr * NB + c] : A[(int64_t)(jb * NB + rr) * P.ld + jb * NB + c];
+  };
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int rr = r0 + half;
+  for (; rr + 6 < r1; rr += 8) {                           // four independent loads in flight per lane
+    const double v0 = ld(rr), v1 = ld(rr + 2), v2 = ld(rr + 4), v3 = ld(rr + 6);
+    s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
   }
+  for (; rr < r1; rr += 2) { const double v0 = ld(rr); s0 += v0 * v0; }
+  const double s = (s0 + s1) + (s2 + s3);
   __shared__ double red[NB];
   if (half == 1) red[c] = s;
   __syncthreads();
@@ -809,18 +841,20 @@ __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
 // ---------------------------------------------------------------------------
 // mll = -(||z||^2 + log det A + n log 2 pi) / 2n ;  gradients from the partials.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(PgmDev P) {
+constexpr int FIN_THREADS = 1024;
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   const int b = blockIdx.z, t = threadIdx.x;
-  __shared__ double red[4];
+  __shared__ double red[FIN_THREADS / 64];
   const int bad = P.info[b];
   double s = 0.0;
-  for (int i = t; i < P.np; i += NTHREADS) { const double zi = P.z[b * P.sVec + i]; s += zi * zi; }
-  for (int kk = t; kk < P.nb; kk += NTHREADS) s += P.logdet[b * P.sLogdet + kk];
+  for (int i = t; i < P.np; i += FIN_THREADS) { const double zi = P.z[b * P.sVec + i]; s += zi * zi; }
+  for (int kk = t; kk < P.nb; kk += FIN_THREADS) s += P.logdet[b * P.sLogdet + kk];
   s = wave_sum(s);
   if ((t & 63) == 0) red[t >> 6] = s;
   __syncthreads();
   if (t == 0) {
-    const double tot = red[0] + red[1] + red[2] + red[3];
+    double tot = 0.0;
+    for (int wv = 0; wv < FIN_THREADS / 64; ++wv) tot += red[wv];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     P.mll[b] = bad ? nan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
     if (P.info_out) P.info_out[b] = bad;
@@ -829,11 +863,16 @@ __global__ __launch_bounds__(256) void k_finalize(PgmDev P) {
   const double half_n = 0.5 / (double)P.n;
   const int Q = P.q, QD = P.qd;
   const int wave = t >> 6, lane = t & 63;
-  for (int sidx = wave; sidx < P.nslot; sidx += NTHREADS / 64) {
-    double acc = 0.0;
+  for (int sidx = wave; sidx < P.nslot; sidx += FIN_THREADS / 64) {
     const double* part = P.partials + b * P.sPart + sidx;
-    for (int tile = lane; tile < P.nitems; tile += 64) acc += part[(int64_t)tile * P.nslot];
-    acc = wave_sum(acc);                       // fixed summation order: reproducible
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int tile = lane;
+    for (; tile + 192 < P.nitems; tile += 256) {
+      a0 += part[(int64_t)tile * P.nslot]; a1 += part[(int64_t)(tile + 64) * P.nslot];
+      a2 += part[(int64_t)(tile + 128) * P.nslot]; a3 += part[(int64_t)(tile + 192) * P.nslot];
+    }
+    for (; tile < P.nitems; tile += 64) a0 += part[(int64_t)tile * P.nslot];
+    double acc = wave_sum((a0 + a1) + (a2 + a3));   // fixed summation order: reproducible
     if (lane != 0) continue;
     if (sidx < Q) {
       if (P.g_w) P.g_w[(int64_t)b * Q + sidx] = half_n * acc;
@@ -847,7 +886,7 @@ __global__ __launch_bounds__(256) void k_finalize(PgmDev P) {
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
   }
-  for (int i = t; i < P.n; i += NTHREADS) {
+  for (int i = t; i < P.n; i += FIN_THREADS) {
     const double al = P.alpha[b * P.sVec + i];
     if (P.g_mean) P.g_mean[(int64_t)b * P.n + i] = al / (double)P.n;
     if (P.g_noise) {
@@ -877,7 +916,7 @@ __global__ __launch_bounds__(256) void k_sm_dense(const double* x1, int64_t n1, 
       const double a = x1[i * d + dd], c = x2[j * d + dd];
       const double m = mu[qq * d + dd], s = v[qq * d + dd];
       const double ds = a * s - c * s;
-      const double e = exp(-TWO_PI_SQ * ds * ds) * cospi(2.0 * (a * m - c * m));
+      const double e = exp_neg(-TWO_PI_SQ * ds * ds) * cospi(2.0 * (a * m - c * m));
       if (dim_order == 0) S[dd] += w[qq] * e; else prod *= e;
     }
     if (dim_order != 0) K1 += w[qq] * prod;
