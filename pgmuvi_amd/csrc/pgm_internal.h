@@ -14,7 +14,7 @@ struct PgmDev {
   int n, np, nb, q, d, qd, dim_order, need_grad, batch;
   int nslot, ntiles, pre_slots, nitems;
   int64_t ld;                                   // == np
-  int64_t sA, sDinv, sPre, sVec, sPart, sLogdet, sDpart;
+  int64_t sA, sDinv, sPre, sVec, sPart, sLogdet, sDpart, sOut;
   double* A;          // [batch][np*np]  upper blocks: K+noise -> U ; strictly lower blocks: V = U^-T
   double* Dinv;       // [batch][nb][2][NB*NB]  0: Uinv_kk ([p][m])   1: Uinv_kk^T = V_kk ([k][n])
   double* pre;        // [batch][3*qd + d][np]  cos, sin, x*v per (q,d); raw x per d
@@ -25,7 +25,11 @@ struct PgmDev {
   double* partials;   // [batch][nitems][nslot]
   double* dpart;      // [batch][AINV_SPLITS][np]  partial column sums of squares of V
   const int4* items;  // [nitems] (i, j, first k-block, k-blocks) of the inverse/gradient pass
-  double* hyp;        // [batch][q + 2*q*d] copy of (w, mu, v) kept for prediction
+  double* hyp;        // [batch][3*PGM_MAX_QD] copy of (w, mu, v): the in-graph kernels and prediction read this
+  double* diagadd;    // [batch][np]  noise_i + scalar noise + jitter
+  double* out_small;  // [batch][1 + q + 2*q*d (+pad)]  mll, g_w, g_mu, g_v
+  double* out_gnoise; // [batch][np]
+  double* out_gmean;  // [batch][np]
   int* info;          // [batch]
   double jitter, noise_scalar;
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
@@ -40,7 +44,7 @@ struct pgm_ws {
   int64_t max_n, max_np;
   int max_q, max_d, max_batch, max_nb;
   size_t bytes;
-  double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp, *dpart;
+  double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp, *dpart, *diagadd, *out_small, *out_gnoise, *out_gmean;
   int* info;
   int4* items;           // device copy of the work-item table
   std::vector<int4> items_host;
@@ -51,6 +55,11 @@ struct pgm_ws {
   double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128)
+  // hipGraph replay of the launch sequence between k_precompute and k_stage_out
+  bool use_graph;
+  hipStream_t cap_stream;
+  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
   // profiling
   bool prof_on;
   std::vector<hipEvent_t> ev_pool;

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void k_precompute(PgmDev P) {
   }
   const int64_t vi = (int64_t)b * P.sVec + i;
   P.r[vi] = valid ? (P.y[(int64_t)b * P.n + i] - P.mean[(int64_t)b * P.n + i]) : 0.0;
+  // everything added to the diagonal: fixed noise + scalar noise + jitter (identity on the padding)
+  P.diagadd[vi] = valid ? ((P.noise ? P.noise[(int64_t)b * P.n + i] : 0.0) + P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[b] : 0.0) + P.jitter) : 0.0;
 }
 
 // stage the per-point factor slices of block row `ib` and block column `jb` in LDS
@@ -144,10 +146,9 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   double* wl = cold + P.pre_slots * NB;
   const double* pre = P.pre + b * P.sPre;
   stage_factors(P, pre, ib, jb, rowd, cold);
-  if (threadIdx.x < P.q) wl[threadIdx.x] = P.w[(int64_t)b * P.q + threadIdx.x];
+  if (threadIdx.x < P.q) wl[threadIdx.x] = P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + threadIdx.x];
   __syncthreads();
   double* A = P.A + b * P.sA;
-  const double nsc = P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[b] : 0.0) + P.jitter;
   const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int m = rg + 4 * rr;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
       double val;
       if (gi < P.n && gj < P.n) {
         val = sm_pair<D, ORDER>(rowd, cold, wl, P.q, m, nloc);
-        if (gi == gj) val += nsc + (P.noise ? P.noise[(int64_t)b * P.n + gi] : 0.0);
+        if (gi == gj) val += P.diagadd[b * P.sVec + gi];
       } else {
         val = (gi == gj) ? 1.0 : 0.0;
       }
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
     arow[threadIdx.x] = P.alpha[b * P.sVec + i * NB + threadIdx.x];
     acol[threadIdx.x] = P.alpha[b * P.sVec + j * NB + threadIdx.x];
   }
-  if (threadIdx.x < Q) wl[threadIdx.x] = P.w[(int64_t)b * P.q + threadIdx.x];
+  if (threadIdx.x < Q) wl[threadIdx.x] = P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + threadIdx.x];
   for (int e = threadIdx.x; e < 4 * P.nslot; e += NTHREADS) wpart[e] = 0.0;
   if (nchunks == 1) stage(0, Q); else __syncthreads();
 
@@ -856,12 +857,12 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     double tot = 0.0;
     for (int wv = 0; wv < FIN_THREADS / 64; ++wv) tot += red[wv];
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    P.mll[b] = bad ? nan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
-    if (P.info_out) P.info_out[b] = bad;
+    P.out_small[b * P.sOut + 0] = bad ? nan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
   }
   if (!P.need_grad || bad) return;
   const double half_n = 0.5 / (double)P.n;
   const int Q = P.q, QD = P.qd;
+  const double* hyp = P.hyp + (int64_t)b * (PGM_MAX_QD * 3);
   const int wave = t >> 6, lane = t & 63;
   for (int sidx = wave; sidx < P.nslot; sidx += FIN_THREADS / 64) {
     const double* part = P.partials + b * P.sPart + sidx;
@@ -875,26 +876,50 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     double acc = wave_sum((a0 + a1) + (a2 + a3));   // fixed summation order: reproducible
     if (lane != 0) continue;
     if (sidx < Q) {
-      if (P.g_w) P.g_w[(int64_t)b * Q + sidx] = half_n * acc;
+      P.out_small[b * P.sOut + 1 + sidx] = half_n * acc;
     } else if (sidx < Q + QD) {
       const int qd = sidx - Q, q = qd / P.d;
-      if (P.g_mu) P.g_mu[(int64_t)b * QD + qd] = half_n * (-2.0 * PI) * P.w[(int64_t)b * Q + q] * acc;
+      P.out_small[b * P.sOut + 1 + sidx] = half_n * (-2.0 * PI) * hyp[q] * acc;
     } else if (sidx < Q + 2 * QD) {
       const int qd = sidx - Q - QD, q = qd / P.d;
-      if (P.g_v) P.g_v[(int64_t)b * QD + qd] = half_n * (-2.0 * TWO_PI_SQ) * P.v[(int64_t)b * QD + qd] * P.w[(int64_t)b * Q + q] * acc;
+      P.out_small[b * P.sOut + 1 + sidx] = half_n * (-2.0 * TWO_PI_SQ) * hyp[Q + QD + qd] * hyp[q] * acc;
     }
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
   }
   for (int i = t; i < P.n; i += FIN_THREADS) {
     const double al = P.alpha[b * P.sVec + i];
-    if (P.g_mean) P.g_mean[(int64_t)b * P.n + i] = al / (double)P.n;
-    if (P.g_noise) {
+    P.out_gmean[b * P.sVec + i] = al / (double)P.n;
+    {
       double dsum = 0.0;
 #pragma unroll
       for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
-      P.g_noise[(int64_t)b * P.n + i] = half_n * (al * al - dsum);
+      P.out_gnoise[b * P.sVec + i] = half_n * (al * al - dsum);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Results leave the workspace for the caller's arrays.  Together with k_precompute this is the
+// only kernel that sees caller pointers: everything in between works on workspace addresses
+// only, which is what lets the whole launch sequence be replayed as one hipGraph.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stage_out(PgmDev P) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double* os = P.out_small + b * P.sOut;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) { P.mll[b] = os[0]; if (P.info_out) P.info_out[b] = P.info[b]; }
+    if (P.need_grad) {
+      const int s = threadIdx.x;
+      if (s < P.q) { if (P.g_w) P.g_w[(int64_t)b * P.q + s] = os[1 + s]; }
+      else if (s < P.q + P.qd) { if (P.g_mu) P.g_mu[(int64_t)b * P.qd + (s - P.q)] = os[1 + s]; }
+      else if (s < P.q + 2 * P.qd) { if (P.g_v) P.g_v[(int64_t)b * P.qd + (s - P.q - P.qd)] = os[1 + s]; }
+    }
+  }
+  if (P.need_grad && i < P.n) {
+    if (P.g_mean) P.g_mean[(int64_t)b * P.n + i] = P.out_gmean[b * P.sVec + i];
+    if (P.g_noise) P.g_noise[(int64_t)b * P.n + i] = P.out_gnoise[b * P.sVec + i];
   }
 }
 
