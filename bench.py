@@ -143,21 +143,29 @@ def main():
         step()
     prof = ws.profile_read()
     ws.profile(False)
+    # The trailing update (2N^3/3 flop per evaluation) runs in two kinds of launches: the fused
+    # diagonal-block launches, whose filler workgroups carry most of it (single light curve), and
+    # plain k_update launches (the "head" rows there; all of it in panel mode for batches / big N).
+    fused_ms, fused_launches = prof.get("diag_block+trailing_update", (0.0, 0))
     upd_ms, upd_launches = prof["trailing_update"]
+    upd_ms += fused_ms
+    upd_launches += fused_launches
     flops = update_flops(n) * B * args.steps
     achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-    # HBM-side bytes per launch of this kernel: not measurable from inside the process; taken from the
-    # committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 for gfx950)
+    # memory-side bytes per launch: not measurable from inside the process; taken from the committed
+    # rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 for gfx950)
     traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     if n == 4096 and B == 1 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        rows = [v for k, v in pmc.items() if k.startswith("k_update")]
+        rows = [v for k, v in pmc.items() if k.startswith("k_update") or (fused_launches and k.startswith("k_diag"))]
         tot_l = sum(r["launches"] for r in rows)
         if tot_l:
             traffic = sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot_l
             traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, same workload, earlier run)"
-    roofline = dict(bound="mfma", kernel="trailing_update (k_update: v_mfma_f64_16x16x4_f64 TN tile GEMM)",
+    kname = ("trailing update: fused k_diag launches (diagonal block + filler tiles) + k_update heads"
+             if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN tile GEMM"
+    roofline = dict(bound="mfma", kernel=kname,
                     achieved=round(achieved, 3), peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                     avg_launch_us=round(upd_ms / max(upd_launches, 1) * 1e3, 2), launches_per_eval=upd_launches // args.steps,

@@ -24,8 +24,9 @@ constexpr int NB = 128;   // block size of the blocked algorithms (rows per k-bl
 constexpr int KB = 16;    // k rows staged per LDS chunk
 constexpr int NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1>
+template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1, int NT_ = 256>
 struct TileCfg {
+  static constexpr int NT = NT_;          // threads per workgroup: 4 wavefronts, or 16 for the filler tiles of k_diag
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   // chunks kept in flight in registers ahead of the one being multiplied: a wave of a small tile
   // issues only 16 MFMAs (~0.4 us) per chunk, less than one L2/Infinity-Cache round trip, so a single
@@ -34,14 +35,14 @@ struct TileCfg {
   static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8, "prefetch depth must divide 8 chunks per k-block");
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int WAVES_N = BN / WN;
-  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+  static_assert((BM / WM) * (BN / WN) == NT / 64, "one WM x WN sub-tile per wavefront");
   // LDS row pitch (doubles) == 16 (mod 32): the two k rows a 32-lane group of
   // ds_read_b64 touches land on disjoint halves of the 64 banks.
   static constexpr int PA = BM + 16, PB = BN + 16;
   static constexpr int STAGE = KB * (PA + PB);
   static constexpr int LDS_DOUBLES = 2 * STAGE;
-  static constexpr int VA = KB * BM / 2 / NTHREADS;
-  static constexpr int VB = KB * BN / 2 / NTHREADS;
+  static constexpr int VA = KB * BM / 2 / NT;
+  static constexpr int VB = KB * BN / 2 / NT;
   static_assert(VA >= 1 && VB >= 1, "tile too small for the 16-B staging loads");
 };
 
@@ -81,12 +82,12 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
     ptrs(kb, pa, lda, pb, ldb);
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
-      const int e = t + NTHREADS * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
+      const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
       xa[s] = *reinterpret_cast<const v2d*>(pa + (int64_t)(kr + row) * lda + 2 * c2);
     }
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
-      const int e = t + NTHREADS * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
+      const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
       xb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
     }
   };
@@ -95,12 +96,12 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
     double* Bs = As + KB * C::PA;
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
-      const int e = t + NTHREADS * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
+      const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
       *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = xa[s];
     }
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
-      const int e = t + NTHREADS * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
+      const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
       *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = xb[s];
     }
   };

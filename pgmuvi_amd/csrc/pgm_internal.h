@@ -37,7 +37,7 @@ struct PgmDev {
   int* info_out;
 };
 
-enum PgmPhase { PH_PRE = 0, PH_BUILD, PH_DIAG, PH_TRSM, PH_UPDATE, PH_LAUUM, PH_FINAL, PH_COUNT };
+enum PgmPhase { PH_PRE = 0, PH_BUILD, PH_DIAG, PH_TRSM, PH_UPDATE, PH_LAUUM, PH_FINAL, PH_FUSED, PH_COUNT };
 
 struct pgm_ws {
   int device;
@@ -54,7 +54,7 @@ struct pgm_ws {
   bool last_valid;
   double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
   size_t pred_bytes;
-  int panel;             // block rows per delayed trailing update (k-depth = panel*128)
+  int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;

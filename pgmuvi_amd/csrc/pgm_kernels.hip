@@ -374,7 +374,48 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
   }
 }
 
-__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k) {
+// Filler role of the fused diagonal-block launch.  While workgroup 0 factors block k on one CU
+// (a ~28 us latency-bound chain) the other 255 CUs would idle; instead the same launch carries
+// the trailing update with the previous block row (fill_k = k-1) for every block row >= fill_lo
+// = k+1 -- work that neither this diagonal block nor the following row solve depends on.  A
+// filler workgroup is the same 16 wavefronts as the factoring one and multiplies one 128x128
+// tile at a time, a 32x32 sub-tile per wavefront.
+using CfgFill = TileCfg<128, 128, 32, 32, 1, DIAG_THREADS>;
+static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit the diagonal block image");
+
+// (A persistent variant -- one filler workgroup per CU looping over tiles with the next tile's C
+//  values and first operand chunk prefetched -- was measured and rejected: at 1024 threads the
+//  128-VGPR cap makes the extra 32 registers spill into the multiply loop.)
+__device__ __forceinline__ void diag_filler(const PgmDev& P, double* lds, int fill_k, int fill_lo) {
+  using C = CfgFill;
+  const int b = blockIdx.z;
+  const int nR = P.need_grad ? fill_k + 1 : 0;
+  int tile = (int)blockIdx.x - 1;
+  int r = fill_lo;
+  for (; r < P.nb; ++r) {
+    const int cnt = (P.nb - r) + nR;
+    if (tile < cnt) break;
+    tile -= cnt;
+  }
+  if (r >= P.nb) return;                                     // (uniform for the workgroup)
+  const bool syrk = tile < P.nb - r;
+  const int j = syrk ? r + tile : tile - (P.nb - r);
+  const bool assign = !syrk && j == fill_k;                  // first contribution to this tile of R
+  double* A = P.A + b * P.sA;
+  const int64_t ld = P.ld;
+  const double* pa0 = A + (int64_t)fill_k * NB * ld + r * NB;
+  const double* pb0 = assign ? (P.Dinv + b * P.sDinv + ((int64_t)fill_k * 2 + 1) * NB * NB) : (A + (int64_t)fill_k * NB * ld + j * NB);
+  const int64_t ldb0 = assign ? NB : ld;
+  double* Cp = A + (int64_t)r * NB * ld + j * NB;
+  v4d acc[C::TM][C::TN];
+  if (assign) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
+  }, acc);
+  acc_store<C>(Cp, ld, acc, -1.0);
+}
+
+__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_k, int fill_lo) {
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
@@ -383,6 +424,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k) {
   constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
   __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
   __shared__ int blkcnt[NB / DB];
+  if (blockIdx.x > 0) { diag_filler(P, M, fill_k, fill_lo); return; }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
   if (t < NB / DB) {                                           // thread s builds the list of step s
