@@ -200,7 +200,16 @@ def main():
         for _ in range(k2):
             f2()
         torch.cuda.synchronize()
-        extra["batched"] = {"batch_per_gpu": B2, "evals_per_s": round(B2 * k2 / (time.perf_counter() - t0), 3)}
+        bt = time.perf_counter() - t0
+        ws2.profile(True)
+        for _ in range(2):
+            f2()
+        p2 = ws2.profile_read()
+        ws2.profile(False)
+        u2 = p2["trailing_update"][0] + p2.get("diag_block+trailing_update", (0.0, 0))[0]
+        extra["batched"] = {"batch_per_gpu": B2, "evals_per_s": round(B2 * k2 / bt, 3),
+                            "trailing_update_tflops": round(update_flops(n) * B2 * 2 / (u2 * 1e-3) / 1e12, 2) if u2 > 0 else None,
+                            "trailing_update_frac": round(update_flops(n) * B2 * 2 / (u2 * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 4) if u2 > 0 else None}
         ws = _hip.get_workspace(dev, n, 4, 1, B)
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, cpu_val = cpu_baseline(n, args.cpu_reps)
