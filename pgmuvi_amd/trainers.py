@@ -103,3 +103,124 @@ def train(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=No
                       f" This is < {stop}, so we will end training here.")
                 break
     return results
+
+
+def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10,
+                 stop=None, lr=1e-4, lossfn="mll", optim="SGD", eps=1e-8, stopavg=9, check_every=25, **kwargs):
+    """Device-resident variant of :func:`train`.
+
+    One full iteration -- constraint transforms, the fused HIP evaluation, backward, the optimiser
+    step -- is recorded once as a device graph and replayed; the loss and every parameter are
+    logged into device buffers each iteration and fetched in blocks of ``check_every``
+    iterations, so the per-iteration host synchronisation of the reference loop
+    (``pgmuvi/trainers.py:184-195``) disappears.  Same arguments and ``results`` dictionary as
+    :func:`train`; differences: the stop rule is evaluated every ``check_every`` iterations (on
+    exactly the same window as the reference, so at most ``check_every - 1`` extra iterations
+    run), a failed factorisation surfaces as a non-finite loss (``NanError``) instead of the
+    jitter retry, and ``optim`` must be one of the string choices.
+    """
+    from .gpytorch import settings
+    from .gpytorch.utils.errors import NanError
+    if lightcurve is not None:
+        model, likelihood = lightcurve.model, lightcurve.likelihood
+        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
+    elif any(v is None for v in (model, likelihood, train_x, train_y)):
+        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
+                         "and train_y **must** be passed to train().")
+    if lossfn != "mll":
+        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
+    if not train_x.is_cuda:
+        raise RuntimeError("train_device needs the model and data on the GPU")
+    model.train(); likelihood.train()
+    mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    if optim == "SGD":
+        optimizer = torch.optim.SGD(params, lr=lr)
+    elif optim == "Adam":
+        optimizer = torch.optim.Adam(params, lr=lr, eps=eps, capturable=True)
+    elif optim == "AdamW":
+        optimizer = torch.optim.AdamW(params, lr=lr, eps=eps, capturable=True)
+    else:
+        raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the device-resident loop.")
+
+    names = [n for n, _ in model.named_parameters()]
+    named = dict(model.named_parameters())
+    dev = train_x.device
+    static_loss = torch.zeros((), dtype=train_y.dtype, device=dev)
+
+    def iteration():
+        optimizer.zero_grad(set_to_none=False)
+        loss = -mll(model(train_x), train_y)
+        loss.backward()
+        optimizer.step()
+        static_loss.copy_(loss.detach())
+
+    with settings.check_cholesky_info(False):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            state = {n: p.detach().clone() for n, p in named.items()}
+            for _ in range(3):                    # warm-up: allocates the workspace, optimiser state, grads
+                iteration()
+            with torch.no_grad():                 # undo the warm-up steps
+                for n, p in named.items():
+                    p.copy_(state[n])
+                for st in optimizer.state.values():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.zero_()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            iteration()
+        with torch.no_grad():                     # capture does not execute, but keep the state pristine anyway
+            for n, p in named.items():
+                p.copy_(state[n])
+
+        results = {"loss": [], "delta_loss": []}
+        if lightcurve is not None:
+            for key, value in lightcurve.get_parameters().items():
+                results[key] = [value.cpu().detach().numpy()]
+        else:
+            for n in names:
+                results[n.split(".")[1] if "raw" in n else n] = []
+                results.setdefault(n, [])
+        loss_hist = torch.zeros(maxiter, dtype=train_y.dtype, device=dev)
+        par_hist = {n: torch.zeros((maxiter,) + tuple(p.shape), dtype=p.dtype, device=dev) for n, p in named.items()}
+        done, stopped = 0, False
+        while done < maxiter and not stopped:
+            blk = min(check_every, maxiter - done)
+            for i in range(done, done + blk):
+                graph.replay()
+                loss_hist[i].copy_(static_loss)
+                for n, p in named.items():
+                    par_hist[n][i].copy_(p.detach())
+            host_loss = loss_hist[done:done + blk].cpu().numpy()          # the only synchronisation of the block
+            if not np.isfinite(host_loss).all():
+                raise NanError("non-finite loss in the device-resident loop (factorisation failed or NaN parameters)")
+            for off in range(blk):
+                i = done + off
+                value = host_loss[off]
+                if i > 0:
+                    results["delta_loss"].append(value - results["loss"][-1])
+                results["loss"].append(value)
+                if stop and i > miniter and np.std(results["loss"][-stopavg:]) < stop:
+                    print(f"Average change in loss over the last {stopavg} iterations was "
+                          f"{np.std(results['loss'][-stopavg:])}.\\n This is < {stop}, so we will end training here.")
+                    stopped = True
+                    blk = off + 1
+                    break
+            done += blk
+        n_done = len(results["loss"])
+        if lightcurve is None:
+            for n in names:
+                h = par_hist[n][:n_done].cpu().numpy()
+                results[n].extend(list(h))
+        else:
+            # the lightcurve's parameter view (constrained, transformed names) at the end of the run;
+            # the per-iteration history is available under the raw parameter names
+            for key, value in lightcurve.get_parameters().items():
+                results[key].append(value.cpu().detach().numpy())
+            for n in names:
+                results[n] = list(par_hist[n][:n_done].cpu().numpy())
+    return results

@@ -41,7 +41,7 @@ def test_ctypes_table_matches_header():
     lib = _hip.load()
     assert _hip.version().startswith("pgmuvi_hip") and "gfx950" in _hip.version()
     assert _hip.max_qd() == 16
-    assert lib.pgm_profile_phases() == 7
+    assert lib.pgm_profile_phases() == 8
     names = [lib.pgm_profile_phase_name(i).decode() for i in range(7)]
     assert "trailing_update" in names and "diag_block" in names
 

@@ -107,3 +107,28 @@ def test_reference_eval_mode_prediction_path():
         print("EVAL_OK")
     """)
     assert "EVAL_OK" in out
+
+
+def test_reference_fit_reproduces_the_notebooks_recorded_result():
+    """The reference's own ``Lightcurve.fit`` (shim + oracle stand-in), run exactly as in the comparison
+    notebook's "pgmuvi 1D" cell, must land where the notebook's recorded output says it landed:
+    ``loss: -1.562``, fitted frequencies ``[0.00665436 0.0151593]`` (tests/golden/make_notebook_pin.py)."""
+    out = _run("""
+        sys.path.insert(0, %r)
+        import make_notebook_pin as nb
+        torch.manual_seed(0)
+        lc = nb.build_lightcurve()
+        assert len(lc.xdata) == nb.NOTEBOOK["nb_n_points"]
+        res = nb.run_fit(lc, ob.mll_value_grad)
+        loss = float(res["loss"][-1])
+        f = np.sort(lc.model.covar_module.mixture_means.detach().numpy().reshape(-1))
+        assert len(res["loss"]) == 1000
+        # the initial state the notebook printed: the constant (= mean of the transformed fluxes) to all
+        # 18 printed digits, the weights to the 4 printed -- i.e. the light curve itself is the notebook's
+        assert abs(float(np.ravel(res["mean_module.constant"][0])[0]) - nb.NOTEBOOK["nb_init_constant"]) < 1e-12
+        assert np.allclose(np.ravel(res["covar_module.mixture_weights"][0]), nb.NOTEBOOK["nb_init_weights"], atol=5e-5)
+        assert abs(loss - nb.NOTEBOOK["nb_final_loss"]) < 6e-3, loss
+        assert np.all(np.abs(f / np.sort(nb.NOTEBOOK["nb_final_freqs"]) - 1) < 1e-3), f
+        print("NOTEBOOK_PIN_OK", loss, f)
+    """ % os.path.join(ROOT, "tests", "golden"))
+    assert "NOTEBOOK_PIN_OK" in out
