@@ -70,6 +70,10 @@ def test_hmc_and_reproducibility_and_batch_independence():
     assert np.array_equal(solo["samples"][0], b["samples"][1])
     with pytest.raises(ValueError):
         mcmc.sample(pot, z0, sampler="Gibbs")
+    # metric initialised from the curvature at the start: exact for a Gaussian with the diagonal of the precision
+    pot2, m2, S2 = _gauss_target()
+    d = mcmc.sample(pot2, m2[None, :] + 0.0, num_samples=5, warmup_steps=0, seed=1, init_metric="curvature")
+    assert np.allclose(d["inverse_mass"][0], 1.0 / np.diag(np.linalg.inv(S2)), rtol=1e-6)
 
 
 def test_divergent_or_infinite_potential_is_rejected_not_propagated():

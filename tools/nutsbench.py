@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pgmuvi_amd import mcmc, synthetic as syn
 
-C = int(os.environ.get("CHAINS", 8)); n = int(os.environ.get("NOBS", 2048)); S = int(os.environ.get("SAMPLES", 30)); W = int(os.environ.get("WARMUP", 30))
+C = int(os.environ.get("CHAINS", 8)); n = int(os.environ.get("NOBS", 2048)); S = int(os.environ.get("SAMPLES", 40)); W = int(os.environ.get("WARMUP", 80))
 dev = torch.device("cuda:0")
 xs, ys, ns, pers = [], [], [], []
 for c in range(C):
@@ -26,9 +26,11 @@ for _ in range(20):
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
 print(f"potential+grad, {C} chains x N={n}: {dt*1e3:.3f} ms per tick = {C/dt:.1f} gradient evaluations/s")
 t0 = time.perf_counter()
-out = mcmc.run_mcmc(x, y, nz, num_mixtures=4, num_samples=S, warmup_steps=W, seed=0, initial_values=init, group_by_chain=True, max_tree_depth=6)
+out = mcmc.run_mcmc(x, y, nz, num_mixtures=4, num_samples=S, warmup_steps=W, seed=0, initial_values=init, group_by_chain=True, max_tree_depth=6,
+                    init_metric="curvature")
 dt = time.perf_counter() - t0
 d = out["_diagnostics"]
+print(f"  = {d['n_leapfrog'].sum() / dt * (W + S) / S:.0f} gradient evaluations/s over the run (sampling-phase leapfrog count scaled to all iterations)")
 print(f"NUTS {C} chains, {W}+{S} iterations: {dt:.1f} s; accept {d['accept_prob'].mean():.3f}, divergent {d['divergent'].mean():.3f}, "
       f"mean leapfrogs/iter {d['n_leapfrog'].mean():.1f}, step sizes {np.round(d['step_size'], 4)}")
 f = out["covar_module.mixture_means_prior"].reshape(C, S, 4)
