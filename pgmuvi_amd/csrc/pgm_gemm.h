@@ -41,9 +41,13 @@ struct TileCfg {
   static constexpr int PA = BM + 16, PB = BN + 16;
   static constexpr int STAGE = KB * (PA + PB);
   static constexpr int LDS_DOUBLES = 2 * STAGE;
-  static constexpr int VA = KB * BM / 2 / NT;
-  static constexpr int VB = KB * BN / 2 / NT;
-  static_assert(VA >= 1 && VB >= 1, "tile too small for the 16-B staging loads");
+  // 16-B staging loads per thread and chunk; a narrow operand (fewer 16-B pieces than threads) is loaded
+  // by the first threads only
+  static constexpr int EA = KB * BM / 2, EB = KB * BN / 2;
+  static constexpr int VA = (EA + NT - 1) / NT;
+  static constexpr int VB = (EB + NT - 1) / NT;
+  static_assert(EA % NT == 0 || EA < NT, "operand A: whole rounds of 16-B loads, or a single partial one");
+  static_assert(EB % NT == 0 || EB < NT, "operand B: whole rounds of 16-B loads, or a single partial one");
 };
 
 struct WavePos {
@@ -83,12 +87,12 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
       const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
-      xa[s] = *reinterpret_cast<const v2d*>(pa + (int64_t)(kr + row) * lda + 2 * c2);
+      if (C::EA >= C::NT || e < C::EA) xa[s] = *reinterpret_cast<const v2d*>(pa + (int64_t)(kr + row) * lda + 2 * c2);
     }
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
       const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
-      xb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
+      if (C::EB >= C::NT || e < C::EB) xb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
     }
   };
   auto sstore = [&](int buf, const v2d (&xa)[C::VA], const v2d (&xb)[C::VB]) {
@@ -97,12 +101,12 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
       const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
-      *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = xa[s];
+      if (C::EA >= C::NT || e < C::EA) *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = xa[s];
     }
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
       const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
-      *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = xb[s];
+      if (C::EB >= C::NT || e < C::EB) *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = xb[s];
     }
   };
 

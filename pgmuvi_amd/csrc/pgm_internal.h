@@ -55,6 +55,7 @@ struct pgm_ws {
   double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
+  int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;

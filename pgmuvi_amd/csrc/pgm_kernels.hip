@@ -380,51 +380,85 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
 // = k+1 -- work that neither this diagonal block nor the following row solve depends on.  A
 // filler workgroup is the same 16 wavefronts as the factoring one and multiplies one 128x128
 // tile at a time, a 32x32 sub-tile per wavefront.
-using CfgFill = TileCfg<128, 128, 32, 32, 1, DIAG_THREADS>;
+#ifndef PGM_FILL_PF
+#define PGM_FILL_PF 1            // deeper register prefetch (2, 4) measured: no change, the filler loop is not latency-bound
+#endif
+using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PF, DIAG_THREADS>;
 static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit the diagonal block image");
 
 // (A persistent variant -- one filler workgroup per CU looping over tiles with the next tile's C
 //  values and first operand chunk prefetched -- was measured and rejected: at 1024 threads the
 //  128-VGPR cap makes the extra 32 registers spill into the multiply loop.)
-__device__ __forceinline__ void diag_filler(const PgmDev& P, double* lds, int fill_k, int fill_lo) {
+//
+// Which finished block rows ("sources") a filler tile of block row r applies is the host's choice,
+// per launch: the last one or two sources before k_end, or none (the row sits this launch out).  One source per
+// launch for every row is the plain schedule; when that makes more tiles than CUs (two rounds of
+// ~23 us each against a 28 us diagonal block) every other row waits one launch and then applies two
+// sources in one pass (k-depth 256: the C tile is read and written once for twice the flops, and
+// the launch needs one round).
+// The plan travels as two bit masks over the block rows (kernel arguments = scalar registers: decoding the
+// tile index must not touch memory): skip bit set = the row sits the launch out, two bit set = it applies
+// sources k_end-2 and k_end-1, else k_end-1 only.
+constexpr int FILL_MAX_NB = 48;
+struct FillPlan { unsigned long long skip, two; };
+
+__device__ __forceinline__ void diag_filler(const PgmDev& P, double* lds, int k_end, int fill_lo, const FillPlan& plan) {
   using C = CfgFill;
   const int b = blockIdx.z;
-  const int nR = P.need_grad ? fill_k + 1 : 0;
+  const int nR = P.need_grad ? k_end : 0;                    // inverse-factor tiles (r, j), j < k_end
   int tile = (int)blockIdx.x - 1;
   int r = fill_lo;
   for (; r < P.nb; ++r) {
-    const int cnt = (P.nb - r) + nR;
+    const int cnt = ((plan.skip >> r) & 1ull) ? 0 : (P.nb - r) + nR;
     if (tile < cnt) break;
     tile -= cnt;
   }
   if (r >= P.nb) return;                                     // (uniform for the workgroup)
+  r = __builtin_amdgcn_readfirstlane(r);
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  const int lo = k_end - 1 - (int)((plan.two >> r) & 1ull);
   const bool syrk = tile < P.nb - r;
   const int j = syrk ? r + tile : tile - (P.nb - r);
-  const bool assign = !syrk && j == fill_k;                  // first contribution to this tile of R
+  const int pstart = (!syrk && j > lo) ? j : lo;             // V_pj vanishes for p < j
+  const bool assign = !syrk && j >= lo;                      // first contribution to this tile of R
   double* A = P.A + b * P.sA;
+  const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
-  const double* pa0 = A + (int64_t)fill_k * NB * ld + r * NB;
-  const double* pb0 = assign ? (P.Dinv + b * P.sDinv + ((int64_t)fill_k * 2 + 1) * NB * NB) : (A + (int64_t)fill_k * NB * ld + j * NB);
-  const int64_t ldb0 = assign ? NB : ld;
   double* Cp = A + (int64_t)r * NB * ld + j * NB;
+  // operand pointers of the (at most two, see run_sweep) k-blocks, fixed before the loop: the multiply
+  // loop of this 16-wave workgroup is short of instruction issue slots, not of MFMA
+  const int nkb = k_end - pstart;
+  const double* pa0 = A + (int64_t)pstart * NB * ld + r * NB;
+  const double* pb0 = assign ? Dv + ((int64_t)j * 2 + 1) * NB * NB : A + (int64_t)pstart * NB * ld + j * NB;
+  const int64_t ldb0 = assign ? NB : ld;
+  const double* pa1 = pa0 + NB * ld;
+  const double* pb1 = A + (int64_t)(pstart + 1) * NB * ld + j * NB;
   v4d acc[C::TM][C::TN];
   if (assign) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
-  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
-    pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
-  }, acc);
+  if (nkb == 1) {
+    gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+      pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
+    }, acc);
+  } else {                                                   // two sources (the host never plans more)
+    gemm_tn<C>(lds, 2, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+      pa = kb ? pa1 : pa0; lda = ld; pb = kb ? pb1 : pb0; ldb = kb ? ld : ldb0;
+    }, acc);
+  }
   acc_store<C>(Cp, ld, acc, -1.0);
 }
 
-__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_k, int fill_lo) {
+__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan) {
   const int b = blockIdx.z;
-  if (P.info[b] != 0) return;
+  // (no early exit on P.info here or in k_trsm / k_update: after a failed pivot the chain kernels just
+  //  carry NaNs -- no address depends on data -- and a dependent scalar load in front of every one of the
+  //  ~95 chained launches costs 0.4 us each, 1.5 % of an evaluation)
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
   __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], red[DIAG_WAVES], dump[64], pbuf[4 * 32];
   constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
   __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
   __shared__ int blkcnt[NB / DB];
-  if (blockIdx.x > 0) { diag_filler(P, M, fill_k, fill_lo); return; }
+  if (blockIdx.x > 0) { diag_filler(P, M, fill_end, fill_lo, plan); return; }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
   if (t < NB / DB) {                                           // thread s builds the list of step s
@@ -557,7 +591,10 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   if (t == 0) P.logdet[b * P.sLogdet + k] = red[0] + red[1];
 #ifdef PGM_DIAG_STAMPS
   STAMP();
-  if (t == 0 && k == 0) { for (int q = 0; q < sn_; ++q) P.partials[q] = (double)(st_[q] - st_[0]); P.partials[40] = sn_; }
+  if (t == 0 && k == 0 && blockIdx.z == 0) {      // clock ticks: start, potrf(0), then per step: barrier, row solve+barrier, update(s+1,s+1), potrf(s+1)
+    for (int q = 0; q < sn_; ++q) printf("%d ", (int)(st_[q] - st_[0]));
+    printf("\n");
+  }
 #endif
 }
 
@@ -567,11 +604,13 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
 // Epilogue: the forward substitution rides along,  r_j -= U_kj^T z_k  (j > k), and
 // so does alpha,  alpha_j += V_kj^T z_k  (j < k).
 // ---------------------------------------------------------------------------
-using CfgTrsm = TileCfg<128, 32, 32, 32, 4>;
-__global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
-  using C = CfgTrsm;
+using CfgTrsm = TileCfg<128, 32, 32, 32, 4>;               // (prediction right-hand sides)
+// 8 wavefronts, a 32x16 sub-tile each: the launch sits on the chain and is bound by its own latency, so the
+// multiply body is cut to 64 MFMAs per wavefront (2 us) rather than sized for operand reuse
+using CfgTrsmChain = TileCfg<128, 32, 32, 16, 4, 512>;
+__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k) {
+  using C = CfgTrsmChain;
   const int b = blockIdx.z;
-  if (P.info[b] != 0) return;
   const int slab = blockIdx.x & 3;
   int jb = blockIdx.x >> 2;
   if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
@@ -580,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
   const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   __shared__ double zs[NB];
-  __shared__ double red[4][C::BN];
+  __shared__ double red[C::NT / 64][C::WN];
   if (threadIdx.x < NB) zs[threadIdx.x] = P.z[b * P.sVec + k * NB + threadIdx.x];
   v4d acc[C::TM][C::TN];
   acc_zero<C>(acc);
@@ -603,8 +642,11 @@ __global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
   }
   __syncthreads();
   if (threadIdx.x < C::BN) {
-    const int c = threadIdx.x;
-    const double tot = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    // column c: the wavefronts of its column group, top to bottom (fixed order)
+    const int c = threadIdx.x, nw = c / C::WN, cc = c % C::WN;
+    double tot = 0.0;
+#pragma unroll
+    for (int mw = 0; mw < C::BM / C::WM; ++mw) tot += red[mw * C::WAVES_N + nw][cc];
     const int64_t g = b * P.sVec + jb * NB + slab * C::BN + c;
     if (jb > k) P.r[g] -= tot; else P.alpha[g] += tot;
   }
@@ -621,9 +663,8 @@ __global__ __launch_bounds__(256, 2) void k_trsm(PgmDev P, int k) {
 // The same kernel with dp=1 and a short row range is the in-panel update.
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi) {
+__global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi) {
   const int b = blockIdx.z;
-  if (P.info[b] != 0) return;
   constexpr int SUB = NB / C::BM;
   static_assert(C::BM == C::BN, "square tiles");
   // (An XCD-aware 8x8 super-block order was measured and rejected at this size: a whole
@@ -668,6 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_update(PgmDev P, int k0, int dp, int
 // ---------------------------------------------------------------------------
 using CfgBig = TileCfg<128, 128, 64, 64>;
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
+using CfgHead = TileCfg<64, 64, 32, 16, 4, 512>;           // the fused sweep's one-row update on the chain: see CfgTrsmChain
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
 constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);          // alpha slices, weights, wave partials
