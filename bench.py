@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 from pgmuvi_amd import _hip, synthetic as syn  # noqa: E402
 from pgmuvi_amd.batch import gather_logliks  # noqa: E402
 
+PMC_FILE = "r01_pmc_hbm_traffic_v2.json"
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet "FP64 matrix" (the guides list no fp64 MFMA figure)
 NB = 128
 
@@ -49,6 +50,14 @@ def update_flops(n):
     nb = (n + NB - 1) // NB
     tiles = sum((nb - 1 - k) * (nb - k) // 2 + (nb - 1 - k) * (k + 1) for k in range(nb))
     return tiles * 2.0 * NB ** 3
+
+
+def trsm_flops(n, need_grad=True):
+    """Row solves of the sweep: block row k multiplies U_kk^-T into its nb-1-k (value only) or nb-1 (with the
+    inverse factor) other 128x128 blocks."""
+    nb = (n + NB - 1) // NB
+    blocks = sum((nb - 1) if need_grad else (nb - 1 - k) for k in range(nb))
+    return blocks * 2.0 * NB ** 3
 
 
 def cpu_baseline(n, reps):
@@ -143,33 +152,46 @@ def main():
         step()
     prof = ws.profile_read()
     ws.profile(False)
-    # The trailing update (2N^3/3 flop per evaluation) runs in two kinds of launches: the fused
-    # diagonal-block launches, whose filler workgroups carry most of it (single light curve), and
-    # plain k_update launches (the "head" rows there; all of it in panel mode for batches / big N).
+    # The dominant kernel is the tile GEMM of the factorisation sweep (trailing update 2N^3/3 flop per evaluation, plus
+    # the row solves).  For a single light curve (fused sweep) its tiles run in all three launch kinds of the chain --
+    # filler workgroups of the k_diag launches, the tail of the k_trsm grids, k_update_rows -- so the achieved rate is
+    # taken over ALL sweep launches (the diagonal-block and row-solve work inside them included in the time); in
+    # panel mode (batches, big N) over the k_update launches as before.
     fused_ms, fused_launches = prof.get("diag_block+trailing_update", (0.0, 0))
     upd_ms, upd_launches = prof["trailing_update"]
-    upd_ms += fused_ms
-    upd_launches += fused_launches
     flops = update_flops(n) * B * args.steps
+    launch_mix = None
+    if fused_launches:
+        trsm_ms, trsm_launches = prof["row_solve"]
+        diag_ms, diag_launches = prof["diag_block"]
+        flops += trsm_flops(n, need_grad=True) * B * args.steps
+        launch_mix = {"k_diag": round((fused_ms + diag_ms) / max(fused_launches + diag_launches, 1) * 1e3, 2),
+                      "k_trsm": round(trsm_ms / max(trsm_launches, 1) * 1e3, 2),
+                      "k_update_rows": round(upd_ms / max(upd_launches, 1) * 1e3, 2)}
+        upd_ms += fused_ms + diag_ms + trsm_ms
+        upd_launches += fused_launches + diag_launches + trsm_launches
     achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
     # memory-side bytes per launch: not measurable from inside the process; taken from the committed
-    # rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 for gfx950)
+    # rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 for gfx950; tools/pmc_traffic.py)
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    pmc_file = os.path.join(ROOT, "profiles", PMC_FILE)
     if n == 4096 and B == 1 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        rows = [v for k, v in pmc.items() if k.startswith("k_update") or (fused_launches and k.startswith("k_diag"))]
+        rows = [v for k, v in pmc.items() if k.startswith("k_update") or (fused_launches and (k.startswith("k_diag") or k.startswith("k_trsm")))]
         tot_l = sum(r["launches"] for r in rows)
         if tot_l:
             traffic = sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot_l
-            traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, same workload, earlier run)"
-    kname = ("trailing update: fused k_diag launches (diagonal block + filler tiles) + k_update heads"
-             if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN tile GEMM"
+            traffic_src = f"profiles/{PMC_FILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, same workload, earlier run)"
+    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles; k_trsm: row solve + update tiles; "
+             "k_update_rows): trailing-update + row-solve tile GEMM"
+             if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN"
     roofline = dict(bound="mfma", kernel=kname,
                     achieved=round(achieved, 3), peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                     avg_launch_us=round(upd_ms / max(upd_launches, 1) * 1e3, 2), launches_per_eval=upd_launches // args.steps,
-                    flops_per_eval=update_flops(n) * B)
+                    flops_per_eval=flops / args.steps)
+    if launch_mix:
+        roofline["avg_launch_us_by_kernel"] = launch_mix
     phases = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
 
     result = None

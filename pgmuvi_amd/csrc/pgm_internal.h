@@ -56,6 +56,7 @@ struct pgm_ws {
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
+  int bh, bt;            // fused sweep: update-tile budgets of the head and row-solve launches (128x128 tiles)
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;

@@ -402,12 +402,19 @@ static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit
 constexpr int FILL_MAX_NB = 48;
 struct FillPlan { unsigned long long skip, two; };
 
-__device__ __forceinline__ void diag_filler(const PgmDev& P, double* lds, int k_end, int fill_lo, const FillPlan& plan) {
-  using C = CfgFill;
+// One planned trailing-update tile (or BM x BN sub-tile of it): workgroup index widx counts the sub-tiles of
+// the planned rows >= r_from in row order.  Used by the filler workgroups of k_diag (128x128, 16 wavefronts)
+// and, with 64x64 sub-tiles on 8 wavefronts, by the chain's two small launches (k_update_rows, the tail of
+// k_trsm's grid), whose idle CUs take part of the trailing update as well.
+template <class C>
+__device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const FillPlan& plan, int k_end, int r_from, int widx) {
+  constexpr int SUBM = NB / C::BM, SUBN = NB / C::BN;
   const int b = blockIdx.z;
   const int nR = P.need_grad ? k_end : 0;                    // inverse-factor tiles (r, j), j < k_end
-  int tile = (int)blockIdx.x - 1;
-  int r = fill_lo;
+  const int sub = widx % (SUBM * SUBN);
+  int tile = widx / (SUBM * SUBN);
+  const int si = sub / SUBN, sj = sub % SUBN;
+  int r = r_from;
   for (; r < P.nb; ++r) {
     const int cnt = ((plan.skip >> r) & 1ull) ? 0 : (P.nb - r) + nR;
     if (tile < cnt) break;
@@ -424,15 +431,15 @@ __device__ __forceinline__ void diag_filler(const PgmDev& P, double* lds, int k_
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
-  double* Cp = A + (int64_t)r * NB * ld + j * NB;
+  double* Cp = A + ((int64_t)r * NB + si * C::BM) * ld + j * NB + sj * C::BN;
   // operand pointers of the (at most two, see run_sweep) k-blocks, fixed before the loop: the multiply
-  // loop of this 16-wave workgroup is short of instruction issue slots, not of MFMA
+  // loop of a 16-wave workgroup is short of instruction issue slots, not of MFMA
   const int nkb = k_end - pstart;
-  const double* pa0 = A + (int64_t)pstart * NB * ld + r * NB;
-  const double* pb0 = assign ? Dv + ((int64_t)j * 2 + 1) * NB * NB : A + (int64_t)pstart * NB * ld + j * NB;
+  const double* pa0 = A + (int64_t)pstart * NB * ld + r * NB + si * C::BM;
+  const double* pb0 = (assign ? Dv + ((int64_t)j * 2 + 1) * NB * NB : A + (int64_t)pstart * NB * ld + j * NB) + sj * C::BN;
   const int64_t ldb0 = assign ? NB : ld;
   const double* pa1 = pa0 + NB * ld;
-  const double* pb1 = A + (int64_t)(pstart + 1) * NB * ld + j * NB;
+  const double* pb1 = A + (int64_t)(pstart + 1) * NB * ld + j * NB + sj * C::BN;
   v4d acc[C::TM][C::TN];
   if (assign) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
   if (nkb == 1) {
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
   __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
   __shared__ int blkcnt[NB / DB];
-  if (blockIdx.x > 0) { diag_filler(P, M, fill_end, fill_lo, plan); return; }
+  if (blockIdx.x > 0) { plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, (int)blockIdx.x - 1); return; }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
   if (t < NB / DB) {                                           // thread s builds the list of step s
@@ -608,8 +615,21 @@ using CfgTrsm = TileCfg<128, 32, 32, 32, 4>;               // (prediction right-
 // 8 wavefronts, a 32x16 sub-tile each: the launch sits on the chain and is bound by its own latency, so the
 // multiply body is cut to 64 MFMAs per wavefront (2 us) rather than sized for operand reuse
 using CfgTrsmChain = TileCfg<128, 32, 32, 16, 4, 512>;
-__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k) {
+using CfgHead = TileCfg<64, 64, 32, 16, 4, 512>;           // the chain's update tiles: 64x64 sub-tiles, same reasoning
+constexpr int CHAIN_LDS = CfgTrsmChain::LDS_DOUBLES > CfgHead::LDS_DOUBLES ? CfgTrsmChain::LDS_DOUBLES : CfgHead::LDS_DOUBLES;
+
+// planned trailing-update tiles as their own launch (the fused sweep's head update of block row k, plus
+// whatever else the host's plan puts on this launch's idle CUs)
+__global__ __launch_bounds__(CfgHead::NT, 2) void k_update_rows(PgmDev P, int k_end, int r_from, FillPlan plan) {
+  __shared__ __attribute__((aligned(16))) double lds[CfgHead::LDS_DOUBLES];
+  plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x);
+}
+
+// workgroups >= nslabs of the grid are planned trailing-update tiles riding on this launch's idle CUs
+__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan) {
   using C = CfgTrsmChain;
+  __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
+  if ((int)blockIdx.x >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x - nslabs); return; }
   const int b = blockIdx.z;
   const int slab = blockIdx.x & 3;
   int jb = blockIdx.x >> 2;
@@ -617,7 +637,6 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k) {
   double* A = P.A + b * P.sA;
   double* Cb = A + (int64_t)k * NB * P.ld + jb * NB + slab * C::BN;
   const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
-  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   __shared__ double zs[NB];
   __shared__ double red[C::NT / 64][C::WN];
   if (threadIdx.x < NB) zs[threadIdx.x] = P.z[b * P.sVec + k * NB + threadIdx.x];
@@ -709,7 +728,6 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 // ---------------------------------------------------------------------------
 using CfgBig = TileCfg<128, 128, 64, 64>;
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
-using CfgHead = TileCfg<64, 64, 32, 16, 4, 512>;           // the fused sweep's one-row update on the chain: see CfgTrsmChain
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
 constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);          // alpha slices, weights, wave partials
