@@ -24,26 +24,28 @@ constexpr int NB = 128;   // block size of the blocked algorithms (rows per k-bl
 constexpr int KB = 16;    // k rows staged per LDS chunk
 constexpr int NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1, int NT_ = 256>
+template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1, int NT_ = 256, int KB_ = KB>
 struct TileCfg {
+  static constexpr int KC = KB_;          // k rows staged per LDS chunk (one barrier per chunk)
   static constexpr int NT = NT_;          // threads per workgroup: 4 wavefronts, or 16 for the filler tiles of k_diag
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   // chunks kept in flight in registers ahead of the one being multiplied: a wave of a small tile
   // issues only 16 MFMAs (~0.4 us) per chunk, less than one L2/Infinity-Cache round trip, so a single
   // prefetched chunk leaves the loop latency-bound; PF > 1 hides it
   static constexpr int PF = PF_;
-  static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8, "prefetch depth must divide 8 chunks per k-block");
+  static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8, "prefetch depth must divide the chunks per k-block");
+  static_assert((NB / KB_) % PF_ == 0 && KB_ % 4 == 0, "chunking");
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == NT / 64, "one WM x WN sub-tile per wavefront");
   // LDS row pitch (doubles) == 16 (mod 32): the two k rows a 32-lane group of
   // ds_read_b64 touches land on disjoint halves of the 64 banks.
   static constexpr int PA = BM + 16, PB = BN + 16;
-  static constexpr int STAGE = KB * (PA + PB);
+  static constexpr int STAGE = KC * (PA + PB);
   static constexpr int LDS_DOUBLES = 2 * STAGE;
   // 16-B staging loads per thread and chunk; a narrow operand (fewer 16-B pieces than threads) is loaded
   // by the first threads only
-  static constexpr int EA = KB * BM / 2, EB = KB * BN / 2;
+  static constexpr int EA = KC * BM / 2, EB = KC * BN / 2;
   static constexpr int VA = (EA + NT - 1) / NT;
   static constexpr int VB = (EB + NT - 1) / NT;
   static_assert(EA % NT == 0 || EA < NT, "operand A: whole rounds of 16-B loads, or a single partial one");
@@ -76,12 +78,13 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
                                         v4d (&acc)[C::TM][C::TN]) {
   const int t = threadIdx.x;
   const WavePos wp = wave_pos<C>();
-  const int nchunks = nkb * (NB / KB);
+  constexpr int KC = C::KC;
+  const int nchunks = nkb * (NB / KC);
   constexpr int D = C::PF;
   v2d ra[D][C::VA], rb[D][C::VB];
 
   auto gload = [&](int c, v2d (&xa)[C::VA], v2d (&xb)[C::VB]) {
-    const int kb = c / (NB / KB), kr = (c % (NB / KB)) * KB;
+    const int kb = c / (NB / KC), kr = (c % (NB / KC)) * KC;
     const double* pa; const double* pb; int64_t lda, ldb;
     ptrs(kb, pa, lda, pb, ldb);
 #pragma unroll
@@ -97,7 +100,7 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
   };
   auto sstore = [&](int buf, const v2d (&xa)[C::VA], const v2d (&xb)[C::VB]) {
     double* As = lds + buf * C::STAGE;
-    double* Bs = As + KB * C::PA;
+    double* Bs = As + KC * C::PA;
 #pragma unroll
     for (int s = 0; s < C::VA; ++s) {
       const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
@@ -121,9 +124,9 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
       const int c = c0 + u;
       if (c + D < nchunks) gload(c + D, ra[u], rb[u]);       // set u is free: chunk c already sits in LDS
       const double* As = lds + (c & 1) * C::STAGE;
-      const double* Bs = As + KB * C::PA;
+      const double* Bs = As + KC * C::PA;
 #pragma unroll
-      for (int kk = 0; kk < KB / 4; ++kk) {
+      for (int kk = 0; kk < KC / 4; ++kk) {
         const int krow = kk * 4 + (wp.lane >> 4);
         double a[C::TM], b[C::TN];
 #pragma unroll

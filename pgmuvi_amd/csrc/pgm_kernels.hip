@@ -383,7 +383,10 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
 #ifndef PGM_FILL_PF
 #define PGM_FILL_PF 1            // deeper register prefetch (2, 4) measured: no change, the filler loop is not latency-bound
 #endif
-using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PF, DIAG_THREADS>;
+#ifndef PGM_FILL_KB
+#define PGM_FILL_KB 16
+#endif
+using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PF, DIAG_THREADS, PGM_FILL_KB>;
 static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit the diagonal block image");
 
 // (A persistent variant -- one filler workgroup per CU looping over tiles with the next tile's C
@@ -461,11 +464,17 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   //  ~95 chained launches costs 0.4 us each, 1.5 % of an evaluation)
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
-  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], red[DIAG_WAVES], dump[64], pbuf[4 * 32];
+  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], dump[64], pbuf[4 * 32];
   constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
   __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
   __shared__ int blkcnt[NB / DB];
-  if (blockIdx.x > 0) { plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, (int)blockIdx.x - 1); return; }
+#ifdef PGM_DIAG_STAMPS
+  const long long entry_ = __builtin_amdgcn_s_memtime();
+#endif
+  if (blockIdx.x > 0) {
+    plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, (int)blockIdx.x - 1);
+    return;
+  }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
   if (t < NB / DB) {                                           // thread s builds the list of step s
@@ -489,9 +498,19 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   c.info = P.info + b;
   c.kbase = k * NB;
   // load the block (upper part is meaningful), clear the inverse images, fetch r_k
-  for (int e = t; e < NB * NB / 2; e += DIAG_THREADS) {
-    const int row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
-    *reinterpret_cast<v2d*>(M + row * PM + c2) = *reinterpret_cast<const v2d*>(c.Akk + (int64_t)row * P.ld + c2);
+  {  // all eight 16-B loads of a thread in flight at once (one memory round trip, not eight)
+    constexpr int NV = NB * NB / 2 / DIAG_THREADS;
+    v2d tmp[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+      tmp[u] = *reinterpret_cast<const v2d*>(c.Akk + (int64_t)row * P.ld + c2);
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+      *reinterpret_cast<v2d*>(M + row * PM + c2) = tmp[u];
+    }
   }   // (the zero triangles of the inverse images are cleared once, at workspace creation)
   if (t < NB) { rsv[t] = P.r[b * P.sVec + k * NB + t]; alv[t] = 0.0; }
   __syncthreads();
@@ -506,6 +525,8 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   if (wave == 0) diag_potrf16(c, 0, lane);
   STAMP();
   constexpr int NS = NB / DB;
+  double lgsum = 0.0;          // (bookkeeping wave)
+  int firstbad = -1;
   for (int s = 0; s < NS; ++s) {
     lds_barrier();
     STAMP();
@@ -555,6 +576,27 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
           }
           if (jb > s) rsv[colg] -= acc; else alv[colg] += acc;
         }
+        // ... and the block's share of log det A and the pivot check ride here too, one 16x16 sub-block per
+        // step, so that nothing but stores is left after the last step
+        {
+          const double u = udg[s * DB + (lane & 15)];
+          const unsigned long long badm = __ballot(!(u > 0.0 && u < 1e300)) & 0xffffull;
+          if (badm && firstbad < 0) firstbad = s * DB + (int)__builtin_ctzll(badm);
+          if (lane < DB) lgsum += 2.0 * log(u);
+        }
+        if (s == NS - 1) {                                  // z_k, alpha_k, log det, info: final now
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            P.z[b * P.sVec + k * NB + lane + 64 * u] = zsv[lane + 64 * u];
+            P.alpha[b * P.sVec + k * NB + lane + 64 * u] = alv[lane + 64 * u];
+          }
+          const double tot = wave_sum(lgsum);
+          if (lane == 0) {
+            P.logdet[b * P.sLogdet + k] = tot;
+            // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
+            if (firstbad >= 0 && *c.info == 0) *c.info = c.kbase + 1 + firstbad;
+          }
+        }
       }
       // trailing sub-blocks of step s from the precomputed list (instruction issue, not MFMA, is
       // what this kernel runs out of: no per-block decoding here), dealt over the worker waves
@@ -580,25 +622,10 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
     if (lane == 0 && k == 0 && s < 4) { P.partials[64 + wave * 16 + s * 2] = (double)(wb1_ - wb0_); P.partials[64 + wave * 16 + s * 2 + 1] = (double)(__builtin_amdgcn_s_memtime() - wc0_); }
 #endif
   }
-  __syncthreads();
-  if (t < NB) {
-    P.z[b * P.sVec + k * NB + t] = zsv[t];
-    P.alpha[b * P.sVec + k * NB + t] = alv[t];
-  }
-  // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
-  if (t < 64) {
-    const bool bad0 = !(udg[t] > 0.0 && udg[t] < 1e300), bad1 = !(udg[t + 64] > 0.0 && udg[t + 64] < 1e300);
-    const unsigned long long m0 = __ballot(bad0), m1 = __ballot(bad1);
-    if (t == 0 && (m0 | m1) && *c.info == 0) *c.info = c.kbase + 1 + (m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1));
-  }
-  double lg = (t < NB) ? 2.0 * log(udg[t]) : 0.0;
-  lg = wave_sum(lg);
-  if (lane == 0) red[wave] = lg;
-  __syncthreads();
-  if (t == 0) P.logdet[b * P.sLogdet + k] = red[0] + red[1];
 #ifdef PGM_DIAG_STAMPS
   STAMP();
-  if (t == 0 && k == 0 && blockIdx.z == 0) {      // clock ticks: start, potrf(0), then per step: barrier, row solve+barrier, update(s+1,s+1), potrf(s+1)
+  if (t == 0 && (k == 0 || k == 3 || k == 25) && blockIdx.z == 0) {      // clock ticks: start, potrf(0), then per step: barrier, row solve+barrier, update(s+1,s+1), potrf(s+1)
+    printf("k=%d entry->first stamp %d: ", k, (int)(st_[0] - entry_));
     for (int q = 0; q < sn_; ++q) printf("%d ", (int)(st_[q] - st_[0]));
     printf("\n");
   }
