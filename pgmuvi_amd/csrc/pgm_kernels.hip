@@ -753,7 +753,10 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 // recomputed from the per-point factors, leaving one partial sum per hyper-
 // parameter and tile (summed in fixed order by k_finalize: bitwise reproducible).
 // ---------------------------------------------------------------------------
-using CfgBig = TileCfg<128, 128, 64, 64>;
+#ifndef PGM_BIG_PF
+#define PGM_BIG_PF 1
+#endif
+using CfgBig = TileCfg<128, 128, 64, 64, PGM_BIG_PF>;
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
@@ -976,6 +979,22 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   const int b = blockIdx.z, t = threadIdx.x;
   __shared__ double red[FIN_THREADS / 64];
   const int bad = P.info[b];
+  // workgroup 0: the scalars (mll, hyper-parameter gradients); workgroups 1..: the per-point gradients
+  // (mean and noise), FIN_THREADS points each -- side by side instead of one after the other
+  if (blockIdx.x > 0) {
+    if (!P.need_grad || bad) return;
+    const double half_n = 0.5 / (double)P.n;
+    const int i = ((int)blockIdx.x - 1) * FIN_THREADS + t;
+    if (i < P.n) {
+      const double al = P.alpha[b * P.sVec + i];
+      P.out_gmean[b * P.sVec + i] = al / (double)P.n;
+      double dsum = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
+      P.out_gnoise[b * P.sVec + i] = half_n * (al * al - dsum);
+    }
+    return;
+  }
   double s = 0.0;
   for (int i = t; i < P.np; i += FIN_THREADS) { const double zi = P.z[b * P.sVec + i]; s += zi * zi; }
   for (int kk = t; kk < P.nb; kk += FIN_THREADS) s += P.logdet[b * P.sLogdet + kk];
@@ -1015,16 +1034,6 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     }
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
-  }
-  for (int i = t; i < P.n; i += FIN_THREADS) {
-    const double al = P.alpha[b * P.sVec + i];
-    P.out_gmean[b * P.sVec + i] = al / (double)P.n;
-    {
-      double dsum = 0.0;
-#pragma unroll
-      for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
-      P.out_gnoise[b * P.sVec + i] = half_n * (al * al - dsum);
-    }
   }
 }
 
