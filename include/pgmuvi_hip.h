@@ -128,6 +128,18 @@ int pgm_profile_phases(void);
 const char* pgm_profile_phase_name(int phase);
 int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
 
+/*
+ * Lomb-Scargle periodogram for the seeding of the mixture frequencies: the
+ * floating-mean ("generalised") periodogram, standard normalisation, exact fp64 sums, of `batch` light curves
+ * (t, y, dy: [batch][n]; dy NULL = unit weights) on one frequency grid freq[nf]; power: [batch][nf];
+ * scratch: [batch][2n+1] doubles of caller-owned device memory.  fit_mean = 1 is astropy's default.
+ * Replaces `LombScargle(t, y, yerr).power(freq)` at pgmuvi/lightcurve.py:4320, 4504-4511 (fit_LS), which
+ * Lightcurve.fit() calls at :5516-5541.
+ */
+int pgm_lomb_scargle_f64(const double* t, const double* y, const double* dy, int64_t n, int batch,
+                         const double* freq, int64_t nf, int fit_mean, double* scratch, double* power,
+                         void* stream);
+
 /* fp64 MFMA issue-rate probe (TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on
  * every CU); used once by bench.py to report the measured peak beside the
  * datasheet figure.  Synchronises. */

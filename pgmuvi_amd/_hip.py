@@ -40,6 +40,8 @@ SYMBOLS = {
     "pgm_profile_phase_name": (c_char_p, [c_int]),
     "pgm_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "pgm_probe_mfma_f64": (c_int, [c_int, POINTER(c_double)]),
+    "pgm_lomb_scargle_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
 }
 
 
@@ -261,3 +263,29 @@ def predict(ws: Workspace, x_test: torch.Tensor, mean_test: torch.Tensor):
         rc = load().pgm_predict_f64(ws.handle, _ptr(xt), _ptr(mt), m, _ptr(pm), _ptr(pv), current_stream_ptr(dev))
     _check(rc, "pgm_predict_f64")
     return pm, pv
+
+
+def lomb_scargle(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], freq: torch.Tensor, fit_mean=True,
+                 center_data=True) -> torch.Tensor:
+    """Floating-mean Lomb-Scargle power (B, Nf) of B light curves (B, N) on one frequency grid (pgm_lomb_scargle_f64).
+    ``center_data`` is implied by ``fit_mean`` (astropy centres in both cases unless both are switched off)."""
+    require_gpu(y, "lomb_scargle")
+    if not (fit_mean or center_data):
+        raise NotImplementedError("fit_mean=False with center_data=False (an uncentred classical periodogram) is not implemented")
+    dev = y.device
+    if y.dim() == 1:
+        t, y = t.reshape(1, -1), y.reshape(1, -1)
+        dy = None if dy is None else dy.reshape(1, -1)
+    B, n = y.shape
+    td = _dev64(t.expand(B, n), dev)
+    yd = _dev64(y, dev)
+    dd = None if dy is None else _dev64(dy.expand(B, n), dev)
+    fd = _dev64(freq.reshape(-1), dev)
+    nf = fd.numel()
+    scratch = torch.empty((B, 2 * n + 1), dtype=torch.float64, device=dev)
+    power = torch.empty((B, nf), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().pgm_lomb_scargle_f64(_ptr(td), _ptr(yd), _ptr(dd), n, B, _ptr(fd), nf, 1 if fit_mean else 0, _ptr(scratch),
+                                         _ptr(power), current_stream_ptr(dev))
+    _check(rc, "pgm_lomb_scargle_f64")
+    return power

@@ -1,0 +1,181 @@
+"""Lomb-Scargle seeding of the spectral-mixture frequencies on the MI355X.
+
+``Lightcurve.fit()`` seeds ``mixture_means`` from the peaks of a Lomb-Scargle periodogram
+(``/root/reference/pgmuvi/lightcurve.py:5516-5541`` -> ``fit_LS``, ``:4214-4611``), which the reference
+computes with ``astropy.timeseries.LombScargle``::
+
+    LS = LombScargle(t, y, yerr); freq = LS.autofrequency(nyquist_factor=5)
+    power = LS.power(freq, assume_regular_frequency=True)
+    LS.false_alarm_probability(power.max(), method='davies'); LS.false_alarm_probability(power[peaks], method='single')
+
+This module provides that class surface on the HIP kernel ``pgm_lomb_scargle_f64`` (exact floating-mean
+periodogram sums, one thread per frequency, batched over light curves) and, for many-light-curve work,
+``periodogram_batched`` / ``seed_frequencies``.  ``install_as_astropy()`` registers a minimal
+``astropy.timeseries`` so that the reference's own ``fit_LS`` runs unmodified where astropy is absent.
+There is no CPU path: the periodogram runs on the GPU or raises.
+
+The periodogram is the published generalised Lomb-Scargle (Zechmeister & Kuerster 2009); astropy's default
+``method='auto'`` approximates the same sums with an FFT (relative differences ~1e-3 in the power, none in
+the peak positions on the 5-samples-per-peak grid).  The false-alarm formulas (Baluev 2008) are restated
+from astropy's published implementation -- unverified against an installed astropy.
+"""
+from __future__ import annotations
+
+import math
+import sys
+import types
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _hip
+
+
+def _np(a):
+    if a is None:
+        return None
+    if torch.is_tensor(a):
+        return a.detach().cpu().numpy().astype(np.float64)
+    return np.asarray(a, dtype=np.float64)
+
+
+def _compute_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pgmuvi_amd.lombscargle evaluates the periodogram with its HIP kernel on an MI355X; "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def periodogram_batched(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], freq: torch.Tensor,
+                        fit_mean=True, center_data=True) -> torch.Tensor:
+    """Standard-normalised floating-mean Lomb-Scargle power, (B, Nf), for B light curves (B, N) on the GPU and
+    one frequency grid (Nf,) shared by the batch."""
+    return _hip.lomb_scargle(t, y, dy, freq, fit_mean, center_data)
+
+
+class LombScargle:
+    """``astropy.timeseries.LombScargle`` as pgmuvi uses it (single term, 'standard' normalisation)."""
+
+    def __init__(self, t, y, dy=None, fit_mean=True, center_data=True, nterms=1, normalization="standard"):
+        if nterms != 1:
+            raise NotImplementedError("only the single-term periodogram pgmuvi uses is implemented")
+        if normalization != "standard":
+            raise NotImplementedError("only normalization='standard' (astropy's default, what pgmuvi uses) is implemented")
+        self.t, self.y, self.dy = _np(t).reshape(-1), _np(y).reshape(-1), None if dy is None else _np(dy).reshape(-1)
+        if self.t.shape != self.y.shape or (self.dy is not None and self.dy.shape != self.t.shape):
+            raise ValueError("t, y, dy must have the same shape")
+        self.fit_mean, self.center_data, self.normalization = fit_mean, center_data, normalization
+
+    # VanderPlas (2018) sec. 7.1 heuristic, astropy's defaults
+    def autofrequency(self, samples_per_peak=5, nyquist_factor=5, minimum_frequency=None, maximum_frequency=None,
+                      return_freq_limits=False):
+        baseline = self.t.max() - self.t.min()
+        n = self.t.size
+        df = 1.0 / baseline / samples_per_peak
+        f0 = 0.5 * df if minimum_frequency is None else float(minimum_frequency)
+        if maximum_frequency is None:
+            maximum_frequency = nyquist_factor * (0.5 * n / baseline)
+        nf = 1 + int(np.round((maximum_frequency - f0) / df))
+        if return_freq_limits:
+            return f0, f0 + df * (nf - 1)
+        return f0 + df * np.arange(nf)
+
+    def power(self, frequency, normalization=None, method="auto", assume_regular_frequency=False, method_kwds=None,
+              fit_mean=None, center_data=None):
+        if normalization not in (None, "standard"):
+            raise NotImplementedError("only normalization='standard'")
+        dev = _compute_device()
+        D = torch.float64
+        f = np.asarray(_np(frequency), dtype=np.float64)
+        shape = f.shape
+        tt = torch.as_tensor(self.t, dtype=D, device=dev).reshape(1, -1)
+        yy = torch.as_tensor(self.y, dtype=D, device=dev).reshape(1, -1)
+        dd = None if self.dy is None else torch.as_tensor(self.dy, dtype=D, device=dev).reshape(1, -1)
+        ff = torch.as_tensor(f.reshape(-1), dtype=D, device=dev)
+        p = periodogram_batched(tt, yy, dd, ff, self.fit_mean if fit_mean is None else fit_mean,
+                                self.center_data if center_data is None else center_data)
+        return p[0].cpu().numpy().reshape(shape)
+
+    # ---- false-alarm probabilities ('standard' normalisation; Baluev 2008 as implemented by astropy)
+    def _fmax(self, samples_per_peak, nyquist_factor, minimum_frequency, maximum_frequency):
+        if maximum_frequency is not None:
+            return float(maximum_frequency)
+        return self.autofrequency(samples_per_peak, nyquist_factor, minimum_frequency, None, return_freq_limits=True)[1]
+
+    def false_alarm_probability(self, power, method="baluev", samples_per_peak=5, nyquist_factor=5,
+                                minimum_frequency=None, maximum_frequency=None, method_kwds=None):
+        z = np.asarray(_np(power), dtype=np.float64)
+        n = self.t.size
+        fs = (1.0 - z) ** (0.5 * (n - 3))
+        if method == "single":
+            return fs
+        fmax = self._fmax(samples_per_peak, nyquist_factor, minimum_frequency, maximum_frequency)
+        w = np.ones_like(self.t) if self.dy is None else self.dy ** -2.0
+        w = w / w.sum()
+        dt = np.dot(w, self.t ** 2) - np.dot(w, self.t) ** 2
+        W = fmax * math.sqrt(4.0 * math.pi * dt)
+        nh, nk = n - 1, n - 3
+        gam = math.sqrt(2.0 / nh) * math.exp(math.lgamma(nh / 2.0) - math.lgamma((nh - 1) / 2.0))
+        tau = gam * W * (1.0 - z) ** (0.5 * (nk - 1)) * np.sqrt(0.5 * nh * z)
+        if method == "davies":
+            return fs + tau
+        if method == "baluev":
+            return 1.0 - (1.0 - fs) * np.exp(-tau)
+        if method == "naive":
+            return 1.0 - (1.0 - fs) ** (fmax * (self.t.max() - self.t.min()))
+        raise NotImplementedError(f"false_alarm_probability method {method!r} (bootstrap needs resampling runs; use "
+                                  "'davies', 'baluev', 'naive' or 'single')")
+
+
+class LombScargleMultiband:
+    """Importable placeholder (``pgmuvi/multiband_ls_significance.py:9`` imports the name at module level)."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("the multiband periodogram is outside the scope of pgmuvi_amd (1-D Lomb-Scargle seeding only)")
+
+
+def seed_frequencies(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], num_peaks=1, nyquist_factor=5,
+                     samples_per_peak=5):
+    """Batched seeding for many light curves (B, N) that share one sampling span: the ``num_peaks`` highest
+    periodogram peaks of each (peaks at least ``nyquist_factor`` grid points apart, like
+    ``find_peaks(power, distance=Nyquist_factor)`` in ``fit_LS``).  Returns (freqs (B, num_peaks), powers, grid)."""
+    from scipy.signal import find_peaks
+    B, n = y.shape
+    tmin, tmax = float(t.min()), float(t.max())
+    baseline = tmax - tmin
+    df = 1.0 / baseline / samples_per_peak
+    f0 = 0.5 * df
+    nf = 1 + int(np.round((nyquist_factor * 0.5 * n / baseline - f0) / df))
+    grid = f0 + df * torch.arange(nf, dtype=torch.float64, device=y.device)
+    P = periodogram_batched(t, y, dy, grid).cpu().numpy()
+    g = grid.cpu().numpy()
+    freqs = np.full((B, num_peaks), np.nan)
+    pows = np.full((B, num_peaks), np.nan)
+    for b in range(B):
+        pk, _ = find_peaks(P[b], distance=nyquist_factor)
+        pk = pk[np.argsort(P[b][pk])][::-1][:num_peaks]
+        freqs[b, :len(pk)] = g[pk]
+        pows[b, :len(pk)] = P[b][pk]
+    return freqs, pows, g
+
+
+def install_as_astropy(force=False):
+    """Registers a minimal ``astropy.timeseries`` (LombScargle on the HIP kernel, LombScargleMultiband as an
+    importable placeholder) so that ``pgmuvi``'s ``fit_LS`` / default ``fit()`` seeding run where astropy is not
+    installed.  Does nothing if a real astropy is importable, unless ``force``."""
+    if not force:
+        try:
+            import astropy.timeseries  # noqa: F401
+            return False
+        except Exception:
+            pass
+    pkg = types.ModuleType("astropy")
+    pkg.__path__ = []
+    ts = types.ModuleType("astropy.timeseries")
+    ts.LombScargle = LombScargle
+    ts.LombScargleMultiband = LombScargleMultiband
+    pkg.timeseries = ts
+    sys.modules["astropy"] = pkg
+    sys.modules["astropy.timeseries"] = ts
+    return True

@@ -65,6 +65,16 @@ def build_lightcurve():
     return LC(lc_2d.xdata[sel][:, 0], lc_2d.ydata[sel], yerr=lc_2d.yerr[sel]).double()
 
 
+def run_fit_ls_seeded(lc, backend, ls_backend, max_iter=1000):
+    """The notebook's fit cell exactly as written (no ``guess``): the initial frequencies come from the reference's
+    own ``fit_LS`` through the astropy-shaped shim (``pgmuvi_amd.lombscargle.install_as_astropy``)."""
+    import torch
+    from pgmuvi_amd import _hip, lombscargle
+    with mock.patch.object(_hip, "mll_value_grad", backend), mock.patch.object(_hip, "lomb_scargle", ls_backend), \
+            mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+        return lc.fit(model="1D", num_mixtures=2, training_iter=max_iter, miniter=50, lr=0.05)
+
+
 def run_fit(lc, backend):
     """The notebook's fit cell, initial frequencies/scales re-entered from the printout."""
     from pgmuvi_amd import _hip

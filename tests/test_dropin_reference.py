@@ -132,3 +132,26 @@ def test_reference_fit_reproduces_the_notebooks_recorded_result():
         print("NOTEBOOK_PIN_OK", loss, f)
     """ % os.path.join(ROOT, "tests", "golden"))
     assert "NOTEBOOK_PIN_OK" in out
+
+
+def test_reference_default_fit_seeds_from_lomb_scargle_like_the_notebook():
+    """``fit()`` without ``periods``/``guess``: the reference's own ``fit_LS`` (lightcurve.py:4214-4611) runs on the
+    astropy-shaped shim (periodogram by the oracle stand-in here, by the HIP kernel on the GPU) and seeds the mixture
+    means with the two frequencies the notebook printed before training: 0.0067 and 0.0154."""
+    out = _run("""
+        sys.path.insert(0, %r)
+        from pgmuvi_amd import lombscargle
+        assert lombscargle.install_as_astropy(force=True)
+        import make_notebook_pin as nb
+        torch.manual_seed(0)
+        lc = nb.build_lightcurve()
+        with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+            f, sig = lc.fit_LS(num_peaks=10)
+        assert bool(sig[0]) and bool(sig[1])
+        assert [round(float(v), 4) for v in f[:2]] == nb.NOTEBOOK["nb_init_means"], f[:4]
+        res = nb.run_fit_ls_seeded(lc, ob.mll_value_grad, ob.lomb_scargle, max_iter=3)
+        init = np.ravel(res["covar_module.mixture_means"][0])
+        assert [round(float(v), 4) for v in init] == nb.NOTEBOOK["nb_init_means"], init
+        print("LS_SEED_OK", f[:2])
+    """ % os.path.join(ROOT, "tests", "golden"))
+    assert "LS_SEED_OK" in out

@@ -73,7 +73,8 @@ def test_golden_fixtures(dev, golden_dir, name):
         k += 1
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 255, 257, 640])
+# (1500, 2900: ragged sizes in the fused sweep, where update tiles ride in all three launch kinds of the chain)
+@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 255, 257, 640, 1500, 2900])
 def test_ragged_sizes_vs_oracle(dev, n):
     gen = torch.Generator().manual_seed(n)
     x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 500)[0]
@@ -506,3 +507,46 @@ def test_nuts_potential_and_short_run_vs_oracle(dev):
     assert np.array_equal(a["_diagnostics"]["n_leapfrog"], b["_diagnostics"]["n_leapfrog"])
     for k in ("covar_module.mixture_means_prior", "covar_module.mixture_weights_prior", "mean_module.mean_prior"):
         assert np.allclose(a[k], b[k], rtol=1e-6, atol=1e-9), k
+
+
+def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
+    """the periodogram kernel behind the astropy-shaped ``LombScargle`` against the numpy
+    oracle -- the notebook's 89-point light curve (whose two highest peaks are the initial frequencies the reference
+    printed, 0.0067 and 0.0154), config 2 at full size with error bars, a batch, unit weights."""
+    from oracle import ls_oracle as lso
+    from pgmuvi_amd import lombscargle as L
+    p = _load(golden_dir, "notebook_pin_1d.npz")
+    t, y, dy = p["x"], p["y"], np.sqrt(p["noise"])
+    ls = L.LombScargle(t, y, dy)
+    f = ls.autofrequency(nyquist_factor=5)
+    pw = ls.power(f, assume_regular_frequency=True)
+    ref = lso.power(t, y, dy, f)
+    assert np.allclose(pw, ref, rtol=1e-9, atol=1e-12)
+    from scipy.signal import find_peaks
+    pk, _ = find_peaks(pw, distance=5)
+    pk = pk[np.argsort(pw[pk])][::-1]
+    assert [round(float(v), 4) for v in f[pk[:2]]] == [round(float(v), 4) for v in p["nb_init_means"]]
+    # full size, with error bars and without
+    tt, yy, ee = syn.cfg2(n_obs=4096)
+    tt, yy, ee = tt.double(), yy.double(), ee.double()
+    grid = torch.as_tensor(lso.autofrequency(tt.numpy()), dtype=D)
+    sub = grid[::37]                                          # the oracle is O(N Nf) in numpy: a slice of the 51k grid
+    for dyv in (ee, None):
+        out = L.periodogram_batched(tt.to(dev).reshape(1, -1), yy.to(dev).reshape(1, -1), None if dyv is None else dyv.to(dev).reshape(1, -1), sub.to(dev))
+        ref = lso.power(tt.numpy(), yy.numpy(), None if dyv is None else dyv.numpy(), sub.numpy())
+        assert np.allclose(out[0].cpu().numpy(), ref, rtol=1e-8, atol=1e-12)
+    full = L.periodogram_batched(tt.to(dev).reshape(1, -1), yy.to(dev).reshape(1, -1), ee.to(dev).reshape(1, -1), grid.to(dev))
+    assert full.shape == (1, grid.numel()) and abs(float(grid[int(full[0].argmax())]) - 1 / 150.0) < 2 * float(grid[1] - grid[0])
+    # batch of different light curves on one grid == singles
+    ts, ys, es = [], [], []
+    for i in range(4):
+        (a, b, c), _ = syn.cfg3_lightcurve(i, n_obs=300)
+        ts.append(a.double()); ys.append(b.double()); es.append(c.double())
+    T, Y, E = torch.stack(ts).to(dev), torch.stack(ys).to(dev), torch.stack(es).to(dev)
+    g2 = torch.linspace(0.001, 0.1, 777, dtype=D).to(dev)
+    PB = L.periodogram_batched(T, Y, E, g2)
+    for i in range(4):
+        assert torch.equal(PB[i], L.periodogram_batched(T[i:i + 1], Y[i:i + 1], E[i:i + 1], g2)[0])
+        assert np.allclose(PB[i].cpu().numpy(), lso.power(ts[i].numpy(), ys[i].numpy(), es[i].numpy(), g2.cpu().numpy()), rtol=1e-9, atol=1e-12)
+    freqs, pows, grid3 = L.seed_frequencies(T, Y, E, num_peaks=3)
+    assert freqs.shape == (4, 3) and np.isfinite(freqs).all()

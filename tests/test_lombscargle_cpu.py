@@ -1,0 +1,84 @@
+"""CPU tests of the Lomb-Scargle seeding layer: the numpy oracle against an independent
+least-squares definition, the astropy-shaped class surface (periodogram by the oracle stand-in: no GPU here), the
+false-alarm formulas' basic properties."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from unittest import mock  # noqa: E402
+
+from oracle import ls_oracle as lso  # noqa: E402
+from pgmuvi_amd import _hip, lombscargle as L, synthetic as syn  # noqa: E402
+import _oracle_backend as ob  # noqa: E402
+
+
+def _data(n=200, seed=3):
+    t, y, e = syn.cfg2(n_obs=n)
+    return t.double().numpy(), y.double().numpy(), e.double().numpy()
+
+
+def test_oracle_equals_the_least_squares_definition():
+    t, y, e = _data()
+    for dy in (e, None):
+        for f in (1 / 400.0, 1 / 150.0, 1 / 67.0, 0.05, 0.31):
+            assert abs(lso.power(t, y, dy, np.array([f]))[0] - lso.power_by_least_squares(t, y, dy, f)) < 1e-10
+
+
+def test_pure_sinusoid_and_grid():
+    rng = np.random.default_rng(0)
+    t = np.sort(rng.uniform(0, 1000, 300))
+    y = 3.0 + 2.0 * np.sin(2 * math.pi * t / 37.0 + 0.4)
+    f = lso.autofrequency(t)
+    base = t.max() - t.min()
+    assert abs(f[0] - 0.1 / base) < 1e-15 and abs((f[1] - f[0]) - 0.2 / base) < 1e-15
+    assert abs(f[-1] - 5 * 0.5 * 300 / base) <= 0.2 / base
+    p = lso.power(t, y, None, f)
+    assert p.max() <= 1.0 + 1e-12 and abs(f[np.argmax(p)] - 1 / 37.0) < 0.2 / base
+    assert p.max() > 0.98                       # (the grid does not hit the frequency exactly)
+    assert lso.power(t, y, None, np.array([1 / 37.0]))[0] > 1 - 1e-12     # noiseless: the sinusoid + floating mean explain everything
+
+
+def test_class_surface_matches_oracle_and_astropy_conventions():
+    t, y, e = _data(150)
+    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(L, "_compute_device", lambda: torch.device("cpu")):
+        ls = L.LombScargle(torch.as_tensor(t), torch.as_tensor(y), torch.as_tensor(e))
+        f = ls.autofrequency(nyquist_factor=5)
+        assert np.allclose(f, lso.autofrequency(t))
+        p = ls.power(f, assume_regular_frequency=True)
+        assert isinstance(p, np.ndarray) and p.shape == f.shape
+        assert np.allclose(p, lso.power(t, y, e, f), rtol=0, atol=1e-13)
+        fap_max = ls.false_alarm_probability(p.max(), method="davies")
+        fap_single = ls.false_alarm_probability(p, method="single")
+        assert np.allclose(fap_single, lso.fap_single(p, t.size))
+        assert abs(fap_max - lso.false_alarm_probability(p.max(), f[-1], t, e, "davies")) < 1e-12 * max(1.0, fap_max)
+        bal = ls.false_alarm_probability(np.array([0.05, 0.3, 0.6]), method="baluev")
+        assert np.all(np.diff(bal) < 0) and np.all((bal >= 0) & (bal <= 1))      # higher peak, smaller FAP
+        with pytest.raises(NotImplementedError):
+            ls.false_alarm_probability(0.5, method="bootstrap")
+    with pytest.raises(NotImplementedError):
+        L.LombScargle(t, y, e, nterms=2)
+    with pytest.raises(NotImplementedError):
+        L.LombScargleMultiband(t, y, t)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.LombScargle(t, y, e).power(np.array([0.01]))          # no GPU here, and no silent CPU path
+
+
+def test_batched_seeding_finds_the_injected_periods():
+    ts, ys, es, per = [], [], [], []
+    for i in range(3):
+        (t, y, e), p = syn.cfg3_lightcurve(i, n_obs=256)
+        ts.append(t.double()); ys.append(y.double()); es.append(e.double()); per.append(p)
+    T, Y, E = torch.stack(ts), torch.stack(ys), torch.stack(es)
+    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle):
+        freqs, pows, grid = L.seed_frequencies(T, Y, E, num_peaks=2)
+    assert freqs.shape == (3, 2) and grid.ndim == 1
+    for b in range(3):        # the leading period (amplitude 1) is the highest peak, to within one grid step
+        assert abs(freqs[b, 0] - 1.0 / per[b]) < 1.5 * (grid[1] - grid[0]), (freqs[b], per[b])
