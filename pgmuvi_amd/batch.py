@@ -65,6 +65,11 @@ def gather_logliks(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    if all(c == counts[0] for c in counts):
+        # equal shards (the usual case): one collective straight into the result, no padding, no list of buffers
+        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     width = max(counts)
     pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: counts[rank]] = local

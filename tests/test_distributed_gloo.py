@@ -40,6 +40,8 @@ def _worker(rank, world, port, q):
     out = evaluate_batch(x[lo:hi], y[lo:hi], m[lo:hi], nz[lo:hi], w[lo:hi], mu[lo:hi], v[lo:hi], _compute=ob.mll_value_grad)
     ll = gather_logliks(out["mll"], B)
     gw = gather_logliks(out["g_w"], B)
+    eq = gather_logliks(torch.full((2, 3), float(rank), dtype=torch.float64), 2 * world)   # equal shards: single-collective path
+    assert eq.shape == (2 * world, 3) and eq[:, 0].tolist() == [float(r) for r in range(world) for _ in range(2)]
     q.put((rank, ll, gw))
     dist.barrier()
     dist.destroy_process_group()
