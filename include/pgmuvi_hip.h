@@ -129,6 +129,23 @@ const char* pgm_profile_phase_name(int phase);
 int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
 
 /*
+ * Dense back-end (the reference's non-spectral-mixture models, pgmuvi/gps.py:915-1342:
+ * quasi-periodic, Matern, RBF, RQ, separable products, sums): the caller supplies a = K + noise as a dense symmetric
+ * matrix ([batch][n][lda], device) and r = y - mean ([batch][n]); mll[batch] is the per-datum log marginal likelihood
+ * (as above), g_a ([batch][n][ldg], symmetric) = dmll/da = (alpha alpha^T - a^-1) / 2n, g_r = dmll/dr = -alpha / n.
+ * Same factorisation sweep as the spectral-mixture path; gradient tiles are accumulated with fp64 atomics
+ * (reproducible to round-off).  Replaces `-mll(model(train_x), train_y)` + `.backward()` (pgmuvi/trainers.py:179-181)
+ * for those models, with autograd pulling g_a back through the torch-built kernel matrix.
+ */
+int pgm_mll_dense_f64(pgm_ws* ws, int batch, const double* a, int64_t lda, const double* r, int64_t n, double jitter,
+                      int need_grad, double* mll, double* g_a, int64_t ldg, double* g_r, int* info, void* stream);
+
+/* Posterior prediction after pgm_mll_dense_f64(need_grad != 0): k_star = K(x_train, x_test) ([n][ldk]), k_ss[n_test] the
+ * prior variances at the test inputs.  Same outputs as pgm_predict_f64. */
+int pgm_predict_dense_f64(pgm_ws* ws, const double* k_star, int64_t ldk, const double* k_ss, const double* mean_test,
+                          int64_t n_test, double* mean_out, double* var_out, void* stream);
+
+/*
  * Lomb-Scargle periodogram for the seeding of the mixture frequencies: the
  * floating-mean ("generalised") periodogram, standard normalisation, exact fp64 sums, of `batch` light curves
  * (t, y, dy: [batch][n]; dy NULL = unit weights) on one frequency grid freq[nf]; power: [batch][nf];

@@ -275,6 +275,57 @@ def nuts_potential(z, x, y, noise, Q, d, c_loc, c_scale, ln_loc=0.0, ln_scale=1.
     return -(total + lp)
 
 
+# ---- the reference's other kernels (pgmuvi/gps.py:915-1342), GPyTorch's published formulas -----------------
+def _sqd(a, b):
+    d = a.unsqueeze(-2) - b.unsqueeze(-3)
+    return (d * d).sum(-1)
+
+
+def rbf(x1, x2, lengthscale):
+    """exp(-|x - x'|^2 / (2 l^2))."""
+    return torch.exp(-0.5 * _sqd(_as_2d(x1) / lengthscale, _as_2d(x2) / lengthscale))
+
+
+def matern(x1, x2, lengthscale, nu):
+    r = (_sqd(_as_2d(x1) / lengthscale, _as_2d(x2) / lengthscale) + 1e-30).sqrt()
+    e = torch.exp(-math.sqrt(2 * nu) * r)
+    if nu == 0.5:
+        return e
+    if nu == 1.5:
+        return (1 + math.sqrt(3.0) * r) * e
+    return (1 + math.sqrt(5.0) * r + 5.0 / 3.0 * r * r) * e
+
+
+def periodic(x1, x2, period, lengthscale):
+    """exp(-2 sin^2(pi (x - x') / p) / lambda), lambda = GPyTorch's (unsquared) lengthscale -- unverified."""
+    d = (_as_2d(x1) * (math.pi / period)).unsqueeze(-2) - (_as_2d(x2) * (math.pi / period)).unsqueeze(-3)
+    return torch.exp((-2.0 * torch.sin(d) ** 2 / lengthscale).sum(-1))
+
+
+def rq(x1, x2, lengthscale, alpha):
+    return (1 + _sqd(_as_2d(x1) / lengthscale, _as_2d(x2) / lengthscale) / (2 * alpha)) ** (-alpha)
+
+
+def mll_dense(K, y, mean, noise, jitter=0.0):
+    """Per-datum MLL for an arbitrary kernel matrix K (dense back-end of the HIP library)."""
+    n = y.shape[0]
+    A = K + torch.diag_embed(_noise_diag(noise, n) + jitter)
+    L = torch.linalg.cholesky(A)
+    r = (y - mean).reshape(n, 1)
+    z = torch.linalg.solve_triangular(L, r, upper=False)
+    return -0.5 * ((z * z).sum() + 2.0 * torch.log(torch.diagonal(L)).sum() + n * LOG_2PI) / n
+
+
+def posterior_dense(K, Ks, kss, y, mean, noise, mean_s):
+    """Posterior mean and latent variance for an arbitrary kernel: K (n,n), Ks = K(x, x*) (n,m), kss (m)."""
+    n = y.shape[0]
+    A = K + torch.diag_embed(_noise_diag(noise, n))
+    L = torch.linalg.cholesky(A)
+    B = torch.linalg.solve_triangular(L, Ks, upper=False)
+    z = torch.linalg.solve_triangular(L, (y - mean).reshape(n, 1), upper=False)
+    return mean_s + (B.T @ z).reshape(-1), kss - (B * B).sum(0)
+
+
 def posterior(x, y, mean, noise, w, mu, v, xs, mean_s, dim_order=0, jitter=0.0):
     """Latent posterior mean and variance at test inputs ``xs``:
         m* + K*^T alpha,   diag(K** - K*^T A^-1 K*).

@@ -40,6 +40,9 @@ SYMBOLS = {
     "pgm_profile_phase_name": (c_char_p, [c_int]),
     "pgm_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "pgm_probe_mfma_f64": (c_int, [c_int, POINTER(c_double)]),
+    "pgm_mll_dense_f64": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p, c_int64,
+                                  c_void_p, c_void_p, c_void_p]),
+    "pgm_predict_dense_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "pgm_lomb_scargle_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p]),
 }
@@ -289,3 +292,48 @@ def lomb_scargle(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], f
                                          _ptr(power), current_stream_ptr(dev))
     _check(rc, "pgm_lomb_scargle_f64")
     return power
+
+
+def mll_dense(A: torch.Tensor, r: torch.Tensor, jitter: float = 0.0, need_grad: bool = True, workspace: Optional[Workspace] = None):
+    """Per-datum MLL of r ~ N(0, A) for a dense symmetric A (n,n) | (B,n,n) built by the caller (any kernel), with
+    dmll/dA and dmll/dr (pgm_mll_dense_f64).  Returns dict(mll, g_a, g_r, info, workspace); no host sync."""
+    require_gpu(A, "mll_dense")
+    dev = A.device
+    batched = A.dim() == 3
+    B = A.shape[0] if batched else 1
+    n = A.shape[-1]
+    Ad = _dev64(A.reshape(B, n, n), dev)
+    rd = _dev64(r.reshape(B, n), dev)
+    ws = workspace or get_workspace(dev, n, 1, 1, B)
+    out = dict(mll=torch.empty(B, dtype=torch.float64, device=dev), info=torch.zeros(B, dtype=torch.int32, device=dev))
+    if need_grad:
+        out["g_a"] = torch.empty((B, n, n), dtype=torch.float64, device=dev)
+        out["g_r"] = torch.empty((B, n), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().pgm_mll_dense_f64(ws.handle, B, _ptr(Ad), n, _ptr(rd), n, float(jitter), 1 if need_grad else 0, _ptr(out["mll"]),
+                                      _ptr(out.get("g_a")), n, _ptr(out.get("g_r")), _ptr(out["info"]), current_stream_ptr(dev))
+    _check(rc, "pgm_mll_dense_f64")
+    out["_keep"] = (Ad, rd)
+    if not batched:
+        for k in ("mll", "info", "g_a", "g_r"):
+            if k in out:
+                out[k] = out[k][0]
+    out["workspace"] = ws
+    return out
+
+
+def predict_dense(ws: Workspace, k_star: torch.Tensor, k_ss: torch.Tensor, mean_test: torch.Tensor):
+    """Posterior mean / latent variance from the factor the last ``mll_dense`` left in ``ws``: k_star = K(x_train, x_test)
+    (n, m), k_ss the prior variances (m)."""
+    require_gpu(k_star, "predict_dense")
+    dev = k_star.device
+    ks = _dev64(k_star, dev)
+    n, m = ks.shape
+    kss = _dev64(k_ss.expand(m).reshape(m), dev)
+    mt = _dev64(mean_test.expand(m).reshape(m), dev)
+    pm = torch.empty(m, dtype=torch.float64, device=dev)
+    pv = torch.empty(m, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().pgm_predict_dense_f64(ws.handle, _ptr(ks), m, _ptr(kss), _ptr(mt), m, _ptr(pm), _ptr(pv), current_stream_ptr(dev))
+    _check(rc, "pgm_predict_dense_f64")
+    return pm, pv

@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(256, 2) void k_pred_update(PgmDev P, int k, double*
 
 __global__ __launch_bounds__(256) void k_pred_reduce(PgmDev P, const double* __restrict__ Ks, int64_t M, int64_t Mp,
                                                      const double* __restrict__ mean_test, double* __restrict__ mean_out,
-                                                     double* __restrict__ var_out) {
+                                                     double* __restrict__ var_out, const double* __restrict__ kss_in) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   double s1 = 0.0, s2 = 0.0;
@@ -1181,6 +1181,7 @@ __global__ __launch_bounds__(256) void k_pred_reduce(PgmDev P, const double* __r
   double kss = wsum;
   if (P.dim_order == 0) for (int dd = 1; dd < P.d; ++dd) kss *= wsum;
   if (mean_out) mean_out[m] = (mean_test ? mean_test[m] : 0.0) + s1;
+  if (kss_in) kss = kss_in[m];                     // dense back-end: prior variances supplied by the caller
   if (var_out) var_out[m] = kss - s2;
 }
 
@@ -1218,6 +1219,121 @@ __global__ __launch_bounds__(256, 2) void k_gemm_probe(const double* A, int64_t 
 #pragma unroll
     for (int tj = 0; tj < C::TN; ++tj) s += acc[ti][tj][0] + acc[ti][tj][3];
   if (s == 1.2345) out[0] = s;
+}
+
+// ---------------------------------------------------------------------------
+// Dense back-end: the caller supplies A = K + noise as a dense symmetric matrix
+// (any kernel: the shim's RBF / Matern / periodic / RQ / products / sums build it with torch), the same sweep
+// factors it, and the gradient leaves as the dense matrix dmll/dA = (alpha alpha^T - A^-1) / 2N for torch's
+// autograd to pull back through whatever built A.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_in(PgmDev P, const double* __restrict__ Ain, int64_t lda,
+                                                  const double* __restrict__ rin) {
+  const int b = blockIdx.z;
+  int ib, jb;
+  tri_decode(blockIdx.x, ib, jb);
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.info[b] = 0;
+  const double* Ab = Ain + (int64_t)b * P.n * lda;
+  double* A = P.A + b * P.sA;
+  const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    const int m = rg + 4 * rr;
+    const int gi = ib * NB + m;
+    v2d out;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int gj = jb * NB + c2 + u;
+      double val;
+      if (gi < P.n && gj < P.n) { val = Ab[(int64_t)gi * lda + gj]; if (gi == gj) val += P.jitter; }
+      else val = (gi == gj) ? 1.0 : 0.0;
+      out[u] = val;
+    }
+    *reinterpret_cast<v2d*>(A + (int64_t)gi * P.ld + jb * NB + c2) = out;
+  }
+  if (ib == jb && threadIdx.x < NB) {
+    const int gi = ib * NB + threadIdx.x;
+    P.r[b * P.sVec + gi] = (gi < P.n) ? rin[(int64_t)b * P.n + gi] : 0.0;
+  }
+}
+
+// Upper-triangle tiles of G = scale * (alpha alpha^T - A^-1), accumulated over the k-split work items of a tile
+// with fp64 atomics (G zeroed beforehand): reproducible to round-off only, unlike the fused SM path.
+__global__ __launch_bounds__(256, 2) void k_lauum_dense(PgmDev P, double* __restrict__ G, int64_t ldg, double scale) {
+  using C = CfgBig;
+  const int b = blockIdx.z;
+  if (P.info[b] != 0) return;
+  const int4 item = P.items[blockIdx.x];
+  const int i = item.x, j = item.y, p0 = item.z, plen = item.w;
+  double* A = P.A + b * P.sA;
+  const double* Dv = P.Dinv + b * P.sDinv;
+  const int64_t ld = P.ld;
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    const int p = p0 + kb;
+    if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB; lda = ld; }
+    else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB; lda = NB; }
+    if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB; ldb = ld; }
+    else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB; ldb = NB; }
+  }, acc);
+  double* arow = lds;
+  double* acol = lds + NB;
+  if (threadIdx.x < NB) {
+    arow[threadIdx.x] = P.alpha[b * P.sVec + i * NB + threadIdx.x];
+    acol[threadIdx.x] = P.alpha[b * P.sVec + j * NB + threadIdx.x];
+  }
+  __syncthreads();
+  const WavePos wp = wave_pos<C>();
+  double* Gb = G + (int64_t)b * P.n * ldg;
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+        const int gi = i * NB + m, gj = j * NB + n;
+        if (gi < P.n && gj < P.n) {
+          const double aa = (p0 == j) ? arow[m] * acol[n] : 0.0;
+          unsafeAtomicAdd(Gb + (int64_t)gi * ldg + gj, scale * (aa - acc[ti][tj][r]));
+        }
+      }
+}
+
+// lower triangle of G <- transpose of the upper one (32x32 blocks through LDS)
+__global__ __launch_bounds__(256) void k_dense_sym(double* __restrict__ G, int64_t ldg, int64_t n) {
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z;
+  const int bi = blockIdx.y, bj = blockIdx.x;           // block (bi, bj) of the LOWER triangle: bi > bj
+  if (bi <= bj) return;
+  double* Gb = G + (int64_t)b * n * ldg;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t gi = (int64_t)bj * 32 + rr, gj = (int64_t)bi * 32 + tx;      // upper block (bj, bi)
+    tile[rr][tx] = (gi < n && gj < n) ? Gb[gi * ldg + gj] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int64_t gi = (int64_t)bi * 32 + rr, gj = (int64_t)bj * 32 + tx;
+    if (gi < n && gj < n) Gb[gi * ldg + gj] = tile[tx][rr];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dense_out(PgmDev P, double* __restrict__ mll, double* __restrict__ g_r, int* __restrict__ info) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { mll[b] = P.out_small[b * P.sOut]; if (info) info[b] = P.info[b]; }
+  if (g_r && i < P.n) g_r[(int64_t)b * P.n + i] = -P.alpha[b * P.sVec + i] / (double)P.n;
+}
+
+// right-hand sides of the dense prediction: the caller's K(x_train, x_test), zero padded
+__global__ __launch_bounds__(256) void k_pred_in(PgmDev P, const double* __restrict__ Kin, int64_t ldk, int64_t M, int64_t Mp,
+                                                 double* __restrict__ Ks) {
+  const int64_t gj = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int gi = blockIdx.y;
+  if (gj >= Mp) return;
+  Ks[(int64_t)gi * Mp + gj] = (gi < P.n && gj < M) ? Kin[(int64_t)gi * ldk + gj] : 0.0;
 }
 
 }  // namespace

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from .lazy import LazySMCovariance, DiagCovariance
+from .lazy import DenseCovariance, DiagCovariance, LazySMCovariance
 
 
 class Distribution:
@@ -78,8 +78,13 @@ class MultivariateNormal(Distribution):
             per_datum = sm_exact_mll(c.x1, value, self.loc, c.noise_vec, c.noise_scalar,
                                      k.mixture_weights, k.mixture_means, k.mixture_scales, k.dim_order)
             return per_datum * n
+        if isinstance(c, DenseCovariance) and c.is_square:
+            # any other kernel: the matrix torch built goes through the same factorisation sweep (dense back-end)
+            from ..mll_function import dense_exact_mll
+            n = value.shape[-1]
+            return dense_exact_mll(c.to_dense(), value - self.loc) * n
         raise NotImplementedError(
-            "pgmuvi_amd only evaluates log_prob for training-mode spectral-mixture exact GPs (the hot path); "
+            "pgmuvi_amd evaluates log_prob for training-mode exact GPs (spectral-mixture: fused; other kernels: dense back-end); "
             f"got covariance of type {type(c).__name__}.")
 
     def __add__(self, other):

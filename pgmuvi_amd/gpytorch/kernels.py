@@ -2,6 +2,8 @@
 for the kernels ``pgmuvi/gps.py:7-19`` imports but the hot path never evaluates."""
 from __future__ import annotations
 
+import math
+
 import torch
 
 from .constraints import Positive
@@ -10,25 +12,91 @@ from .module import Module
 
 
 class Kernel(Module):
+    """Base of every kernel.  ``_dense(x1, x2)`` is the covariance matrix as a torch expression (autograd through the
+    kernel's parameters); ``__call__`` wraps it for the dense back-end.  The spectral-mixture kernel overrides
+    ``forward`` with its lazy object (the fused HIP path) and keeps ``_dense`` for use inside sums and products."""
     has_lengthscale = False
 
-    def __init__(self, ard_num_dims=None, batch_shape=torch.Size(), active_dims=None, **kwargs):
+    def __init__(self, ard_num_dims=None, batch_shape=torch.Size(), active_dims=None, lengthscale_prior=None,
+                 lengthscale_constraint=None, eps=1e-6, **kwargs):
         super().__init__()
         self.ard_num_dims = ard_num_dims
         self.batch_shape = batch_shape
-        self.active_dims = active_dims
+        if active_dims is not None and not torch.is_tensor(active_dims):
+            active_dims = torch.tensor(active_dims, dtype=torch.long)
+        self.register_buffer("active_dims", active_dims)      # (pgmuvi/gps.py:1325-1330 re-registers this buffer)
+        self.eps = eps
+        if self.has_lengthscale:
+            nd = 1 if ard_num_dims is None else ard_num_dims
+            self.register_parameter("raw_lengthscale", torch.nn.Parameter(torch.zeros(*self.batch_shape, 1, nd)))
+            self.register_constraint("raw_lengthscale", lengthscale_constraint or Positive())
+            if lengthscale_prior is not None:
+                self.register_prior("lengthscale_prior", lengthscale_prior, lambda m: m.lengthscale,
+                                    lambda m, v: m._set_lengthscale(v))
 
-    def forward(self, x1, x2, diag=False, **params):
+    @property
+    def lengthscale(self):
+        return self.raw_lengthscale_constraint.transform(self.raw_lengthscale) if self.has_lengthscale else None
+
+    @lengthscale.setter
+    def lengthscale(self, value):
+        self._set_lengthscale(value)
+
+    def _set_lengthscale(self, value):
+        if not self.has_lengthscale:
+            raise RuntimeError("Kernel has no lengthscale.")
+        self._set_raw("raw_lengthscale", value)
+
+    def _set_raw(self, raw_name, value):
+        raw = getattr(self, raw_name)
+        if not torch.is_tensor(value):
+            value = torch.as_tensor(value).to(raw)
+        self.initialize(**{raw_name: self._constraints[raw_name + "_constraint"].inverse_transform(value.to(raw))})
+
+    def _dense(self, x1, x2):
         raise NotImplementedError
 
+    def _select(self, x):
+        if x.ndimension() == 1:
+            x = x.unsqueeze(1)
+        if self.active_dims is not None:
+            x = x.index_select(-1, self.active_dims.to(x.device))
+        return x
+
+    def _dense_active(self, x1, x2):
+        """Matrix of this kernel on its own ``active_dims`` of the full inputs (what sums and products call)."""
+        return self._dense(self._select(x1), self._select(x2))
+
+    def forward(self, x1, x2, diag=False, **params):
+        K = self._dense(x1, x2)
+        return torch.diagonal(K, dim1=-2, dim2=-1) if diag else K
+
     def __call__(self, x1, x2=None, diag=False, **params):
-        if x1.ndimension() == 1:
-            x1 = x1.unsqueeze(1)
-        if x2 is not None and x2.ndimension() == 1:
-            x2 = x2.unsqueeze(1)
-        if x2 is None:
-            x2 = x1
-        return self.forward(x1, x2, diag=diag, **params)
+        from .lazy import DenseCovariance
+        square = x2 is None or x2 is x1
+        x1 = self._select(x1)
+        x2 = x1 if x2 is None else self._select(x2)
+        out = self.forward(x1, x2, diag=diag, **params)
+        if diag or not torch.is_tensor(out):
+            return out
+        return DenseCovariance(out, square or (x1.shape == x2.shape and bool(torch.equal(x1, x2))))
+
+    def __add__(self, other):
+        return AdditiveKernel(self, other)
+
+    def __mul__(self, other):
+        return ProductKernel(self, other)
+
+    @property
+    def is_stationary(self):
+        return self.has_lengthscale
+
+
+def _sq_dist(a, b):
+    """Squared Euclidean distances (n, m) of the rows of a (n, d) and b (m, d), by differences (exact zeros on the
+    diagonal, no cancellation) -- d is 1 or 2 here."""
+    diff = a.unsqueeze(-2) - b.unsqueeze(-3)
+    return (diff * diff).sum(-1)
 
 
 class SpectralMixtureKernel(Kernel):
@@ -113,6 +181,19 @@ class SpectralMixtureKernel(Kernel):
             self.mixture_means = torch.rand_like(self.raw_mixture_means).mul_(0.5).div(min_dist.to(raw))
             self.mixture_weights = train_y.std().div(self.num_mixtures)
 
+    def _dense(self, x1, x2):
+        """The same matrix as a torch expression (only used when the kernel sits inside a sum or product; on its own
+        it takes the fused HIP path).  GPyTorch's evaluation order: scale, then subtract."""
+        w = self.mixture_weights
+        mu, v = self.mixture_means.squeeze(-2), self.mixture_scales.squeeze(-2)       # (Q, d)
+        a1, a2 = x1.unsqueeze(-3) * v.unsqueeze(-2), x2.unsqueeze(-3) * v.unsqueeze(-2)     # (Q, n, d)
+        c1, c2 = x1.unsqueeze(-3) * mu.unsqueeze(-2), x2.unsqueeze(-3) * mu.unsqueeze(-2)
+        e = torch.exp(-2.0 * math.pi ** 2 * (a1.unsqueeze(-2) - a2.unsqueeze(-3)) ** 2)     # (Q, n, m, d)
+        c = torch.cos(2.0 * math.pi * (c1.unsqueeze(-2) - c2.unsqueeze(-3)))
+        if self.dim_order == 0:
+            return (w.reshape(-1, 1, 1, 1) * e * c).sum(0).prod(-1)
+        return (w.reshape(-1, 1, 1) * (e * c).prod(-1)).sum(0)
+
     def forward(self, x1, x2, diag=False, **params):
         d = x1.shape[-1]
         if d != self.ard_num_dims:
@@ -123,23 +204,203 @@ class SpectralMixtureKernel(Kernel):
         return lazy.diagonal_values() if diag else lazy
 
 
+class RBFKernel(Kernel):
+    r"""exp(-1/2 |(x - x') / l|^2)."""
+    has_lengthscale = True
+
+    def _dense(self, x1, x2):
+        l = self.lengthscale
+        return torch.exp(-0.5 * _sq_dist(x1 / l, x2 / l))
+
+
+class MaternKernel(Kernel):
+    r"""Matern with nu in {1/2, 3/2, 5/2}: polynomial(sqrt(2 nu) r) exp(-sqrt(2 nu) r), r = |(x - x') / l|."""
+    has_lengthscale = True
+
+    def __init__(self, nu=2.5, **kwargs):
+        if nu not in {0.5, 1.5, 2.5}:
+            raise RuntimeError("nu expected to be 0.5, 1.5, or 2.5")
+        super().__init__(**kwargs)
+        self.nu = nu
+
+    def _dense(self, x1, x2):
+        l = self.lengthscale
+        r = (_sq_dist(x1 / l, x2 / l) + 1e-30).sqrt()        # (the offset keeps d sqrt / d 0 finite; 1e-15 in r)
+        e = torch.exp(-math.sqrt(2.0 * self.nu) * r)
+        if self.nu == 0.5:
+            return e
+        if self.nu == 1.5:
+            return (1.0 + math.sqrt(3.0) * r) * e
+        return (1.0 + math.sqrt(5.0) * r + 5.0 / 3.0 * r * r) * e
+
+
+class PeriodicKernel(Kernel):
+    r"""exp(-2 sum_i sin^2(pi (x_i - x'_i) / p) / lambda)  -- lambda is GPyTorch's ``lengthscale`` (it enters
+    unsquared in current GPyTorch; restated from its documentation, unverified against an installed copy)."""
+    has_lengthscale = True
+
+    def __init__(self, period_length_prior=None, period_length_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        nd = 1 if self.ard_num_dims is None else self.ard_num_dims
+        self.register_parameter("raw_period_length", torch.nn.Parameter(torch.zeros(*self.batch_shape, 1, nd)))
+        self.register_constraint("raw_period_length", period_length_constraint or Positive())
+        if period_length_prior is not None:
+            self.register_prior("period_length_prior", period_length_prior, lambda m: m.period_length,
+                                lambda m, v: m._set_raw("raw_period_length", v))
+
+    @property
+    def period_length(self):
+        return self.raw_period_length_constraint.transform(self.raw_period_length)
+
+    @period_length.setter
+    def period_length(self, value):
+        self._set_raw("raw_period_length", value)
+
+    def _dense(self, x1, x2):
+        p, lam = self.period_length, self.lengthscale
+        diff = (x1 * (math.pi / p)).unsqueeze(-2) - (x2 * (math.pi / p)).unsqueeze(-3)        # (n, m, d)
+        return torch.exp((-2.0 * torch.sin(diff) ** 2 / lam.unsqueeze(-2)).sum(-1))
+
+
+class CosineKernel(Kernel):
+    r"""cos(pi |x - x'| / p)."""
+
+    def __init__(self, period_length_prior=None, period_length_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        self.register_parameter("raw_period_length", torch.nn.Parameter(torch.zeros(*self.batch_shape, 1, 1)))
+        self.register_constraint("raw_period_length", period_length_constraint or Positive())
+
+    @property
+    def period_length(self):
+        return self.raw_period_length_constraint.transform(self.raw_period_length)
+
+    @period_length.setter
+    def period_length(self, value):
+        self._set_raw("raw_period_length", value)
+
+    def _dense(self, x1, x2):
+        r = (_sq_dist(x1, x2) + 1e-30).sqrt()
+        return torch.cos(math.pi * r / self.period_length.reshape(()))
+
+
+class RQKernel(Kernel):
+    r"""(1 + |(x - x') / l|^2 / (2 alpha))^(-alpha)."""
+    has_lengthscale = True
+
+    def __init__(self, alpha_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        self.register_parameter("raw_alpha", torch.nn.Parameter(torch.zeros(*self.batch_shape, 1)))
+        self.register_constraint("raw_alpha", alpha_constraint or Positive())
+
+    @property
+    def alpha(self):
+        return self.raw_alpha_constraint.transform(self.raw_alpha)
+
+    @alpha.setter
+    def alpha(self, value):
+        self._set_raw("raw_alpha", value)
+
+    def _dense(self, x1, x2):
+        l, al = self.lengthscale, self.alpha.reshape(())
+        return (1.0 + _sq_dist(x1 / l, x2 / l) / (2.0 * al)) ** (-al)
+
+
+class LinearKernel(Kernel):
+    r"""v x x'^T."""
+
+    def __init__(self, variance_prior=None, variance_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        self.register_parameter("raw_variance", torch.nn.Parameter(torch.zeros(*self.batch_shape, 1, 1)))
+        self.register_constraint("raw_variance", variance_constraint or Positive())
+
+    @property
+    def variance(self):
+        return self.raw_variance_constraint.transform(self.raw_variance)
+
+    @variance.setter
+    def variance(self, value):
+        self._set_raw("raw_variance", value)
+
+    def _dense(self, x1, x2):
+        return self.variance.reshape(()) * (x1 @ x2.transpose(-1, -2))
+
+
+class ConstantKernel(Kernel):
+    def __init__(self, constant_prior=None, constant_constraint=None, **kwargs):
+        super().__init__(**kwargs)
+        self.register_parameter("raw_constant", torch.nn.Parameter(torch.zeros(tuple(self.batch_shape))))
+        self.register_constraint("raw_constant", constant_constraint or Positive())
+
+    @property
+    def constant(self):
+        return self.raw_constant_constraint.transform(self.raw_constant)
+
+    @constant.setter
+    def constant(self, value):
+        self._set_raw("raw_constant", value)
+
+    def _dense(self, x1, x2):
+        return self.constant.reshape(()) * torch.ones(x1.shape[-2], x2.shape[-2], dtype=x1.dtype, device=x1.device)
+
+
+class ScaleKernel(Kernel):
+    r"""outputscale * base_kernel."""
+
+    def __init__(self, base_kernel, outputscale_prior=None, outputscale_constraint=None, **kwargs):
+        if getattr(base_kernel, "active_dims", None) is not None:
+            kwargs["active_dims"] = base_kernel.active_dims
+        super().__init__(**kwargs)
+        self.base_kernel = base_kernel
+        self.register_parameter("raw_outputscale", torch.nn.Parameter(torch.zeros(tuple(self.batch_shape))))
+        self.register_constraint("raw_outputscale", outputscale_constraint or Positive())
+        if outputscale_prior is not None:
+            self.register_prior("outputscale_prior", outputscale_prior, lambda m: m.outputscale,
+                                lambda m, v: m._set_raw("raw_outputscale", v))
+
+    @property
+    def outputscale(self):
+        return self.raw_outputscale_constraint.transform(self.raw_outputscale)
+
+    @outputscale.setter
+    def outputscale(self, value):
+        self._set_raw("raw_outputscale", value)
+
+    def _dense(self, x1, x2):
+        # (x1, x2 already carry this kernel's active_dims; the base kernel's own selection applies on top, as in GPyTorch)
+        return self.outputscale.reshape(()) * self.base_kernel._dense_active(x1, x2)
+
+
+class _Composite(Kernel):
+    def __init__(self, *kernels):
+        super().__init__()
+        self.kernels = torch.nn.ModuleList(kernels)
+
+
+class AdditiveKernel(_Composite):
+    def _dense(self, x1, x2):
+        out = None
+        for k in self.kernels:
+            m = k._dense_active(x1, x2)
+            out = m if out is None else out + m
+        return out
+
+
+class ProductKernel(_Composite):
+    def _dense(self, x1, x2):
+        out = None
+        for k in self.kernels:
+            m = k._dense_active(x1, x2)
+            out = m if out is None else out * m
+        return out
+
+
 class _OutOfScopeKernel(Kernel):
-    """Importable placeholder: pgmuvi/gps.py imports these names at module level; none of
-    them is on the spectral-mixture exact-GP hot path."""
+    """Importable placeholder: the structured-kernel-interpolation models of pgmuvi/gps.py (SURVEY.md section 2 rows
+    5-7) are not exact GPs on a dense matrix and stay out of scope."""
 
     def __init__(self, *args, **kwargs):
         raise NotImplementedError(
-            f"{type(self).__name__} is outside the scope of pgmuvi_amd (spectral-mixture exact-GP hot path only)")
+            f"{type(self).__name__} is outside the scope of pgmuvi_amd (exact GPs on the factorisation back-end only)")
 
 
 class GridInterpolationKernel(_OutOfScopeKernel): pass
-class AdditiveKernel(_OutOfScopeKernel): pass
-class ConstantKernel(_OutOfScopeKernel): pass
-class LinearKernel(_OutOfScopeKernel): pass
-class MaternKernel(_OutOfScopeKernel): pass
-class PeriodicKernel(_OutOfScopeKernel): pass
-class ProductKernel(_OutOfScopeKernel): pass
-class RBFKernel(_OutOfScopeKernel): pass
-class RQKernel(_OutOfScopeKernel): pass
-class ScaleKernel(_OutOfScopeKernel): pass
-class CosineKernel(_OutOfScopeKernel): pass

@@ -62,6 +62,61 @@ class LazySMCovariance:
         return self.diagonal_values()
 
 
+class DenseCovariance:
+    """A covariance matrix torch has built (any kernel but the fused spectral-mixture one), with autograd history;
+    noise is kept apart so that ``to_dense`` adds it to the diagonal once."""
+
+    def __init__(self, K, square, noise_vec=None, noise_scalar=None):
+        self.K, self.square = K, square
+        self.noise_vec, self.noise_scalar = noise_vec, noise_scalar
+
+    @property
+    def is_square(self):
+        return self.square
+
+    @property
+    def shape(self):
+        return self.K.shape
+
+    def size(self, dim=None):
+        return self.K.shape if dim is None else self.K.shape[dim]
+
+    def add_noise(self, noise_vec=None, noise_scalar=None):
+        nv, ns = self.noise_vec, self.noise_scalar
+        if noise_vec is not None:
+            nv = noise_vec if nv is None else nv + noise_vec
+        if noise_scalar is not None:
+            ns = noise_scalar if ns is None else ns + noise_scalar
+        return DenseCovariance(self.K, self.square, nv, ns)
+
+    def to_dense(self):
+        K = self.K
+        if self.square and (self.noise_vec is not None or self.noise_scalar is not None):
+            d = torch.zeros(K.shape[-1], dtype=K.dtype, device=K.device)
+            if self.noise_vec is not None:
+                d = d + self.noise_vec
+            if self.noise_scalar is not None:
+                d = d + self.noise_scalar
+            K = K + torch.diag_embed(d)
+        return K
+
+    evaluate = to_dense
+
+    def evaluate_kernel(self):
+        return self
+
+    def diagonal_values(self):
+        out = torch.diagonal(self.K, dim1=-2, dim2=-1)
+        if self.noise_vec is not None:
+            out = out + self.noise_vec
+        if self.noise_scalar is not None:
+            out = out + self.noise_scalar
+        return out
+
+    def diagonal(self, *a, **k):
+        return self.diagonal_values()
+
+
 class DiagCovariance:
     """Pointwise predictive variances (what ``fast_pred_var`` consumers read)."""
 

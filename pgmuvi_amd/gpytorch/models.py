@@ -14,7 +14,7 @@ import torch
 
 from . import settings
 from .distributions import MultivariateNormal
-from .lazy import DiagCovariance, LazySMCovariance
+from .lazy import DenseCovariance, DiagCovariance, LazySMCovariance
 from .likelihoods import _GaussianLikelihoodBase
 from .module import Module
 
@@ -95,14 +95,33 @@ class ExactGP(GP):
             prior = self.forward(train_x)
             marg = self.likelihood(prior)
             c = marg.lazy_covariance_matrix
+            if isinstance(c, DenseCovariance):
+                # dense back-end: factor A once, then K(x_train, x_test) and the prior variances from the kernel itself
+                out = _hip.mll_dense(c.to_dense(), self.train_targets - marg.mean, 0.0, False)
+                if bool((out["info"] != 0).any()):
+                    from .utils.errors import NotPSDError
+                    raise NotPSDError("Matrix not positive definite in eval-mode prediction.")
+                test_prior = self.forward(x_test)
+                cross = self._cross_covariance(train_x, x_test)
+                kss = test_prior.lazy_covariance_matrix.diagonal_values()
+                pm, pv = _hip.predict_dense(out["workspace"], cross, kss, test_prior.mean)
+                return MultivariateNormal(pm.to(x_test.dtype), DiagCovariance(pv.to(x_test.dtype)))
             if not isinstance(c, LazySMCovariance):
-                raise NotImplementedError("posterior prediction is implemented for spectral-mixture exact GPs")
+                raise NotImplementedError("posterior prediction needs an exact GP with a kernel of pgmuvi_amd.gpytorch.kernels")
             k = c.kernel
             out, _ = _evaluate(train_x, self.train_targets, marg.mean, c.noise_vec, c.noise_scalar,
                                k.mixture_weights, k.mixture_means, k.mixture_scales, k.dim_order, True)
             test_prior = self.forward(x_test)
             pm, pv = _hip.predict(out["workspace"], x_test, test_prior.mean)
         return MultivariateNormal(pm.to(x_test.dtype), DiagCovariance(pv.to(x_test.dtype)))
+
+
+    def _cross_covariance(self, x_train, x_test):
+        """K(x_train, x_test) of the model's kernel (``covar_module``; models with another layout override this)."""
+        k = getattr(self, "covar_module", None)
+        if k is None:
+            raise NotImplementedError("eval-mode prediction of a dense-kernel model needs a `covar_module`")
+        return k(x_train, x_test).to_dense()
 
 
 class ApproximateGP(GP):

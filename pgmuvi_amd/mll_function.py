@@ -86,3 +86,53 @@ SMExactMLLFunction.last_jitter = 0.0
 
 def sm_exact_mll(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order=0):
     return SMExactMLLFunction.apply(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order)
+
+
+# ---- dense back-end: any kernel whose matrix torch built ------------------------
+def _evaluate_dense(A, r, need_grad):
+    out = _hip.mll_dense(A, r, 0.0, need_grad)
+    if settings.check_cholesky_info.off():
+        return out, 0.0
+    if not bool((out["info"] != 0).any()):
+        return out, 0.0
+    if bool(torch.isnan(A).any()) or bool(torch.isnan(r).any()):
+        raise NanError("cholesky: NaN in the inputs of the marginal log likelihood.")
+    base = settings.cholesky_jitter.value(torch.float64)
+    jitter = 0.0
+    for i in range(settings.cholesky_max_tries.value()):
+        jitter = base * (10 ** i)
+        warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
+        out = _hip.mll_dense(A, r, jitter, need_grad)
+        if not bool((out["info"] != 0).any()):
+            return out, jitter
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
+
+
+class DenseExactMLLFunction(torch.autograd.Function):
+    """mll per datum = log N(r | 0, A) / N for a dense symmetric A: the factorisation sweep of the hot path on a matrix
+    built elsewhere; backward hands dmll/dA = (alpha alpha^T - A^-1) / 2N and dmll/dr = -alpha / N to autograd."""
+
+    @staticmethod
+    def forward(ctx, A, r):
+        need_grad = any(ctx.needs_input_grad)
+        out, jitter = _evaluate_dense(A, r, need_grad)
+        ctx.dt = (A.dtype, r.dtype)
+        if need_grad:
+            ctx.save_for_backward(out["g_a"], out["g_r"])
+        DenseExactMLLFunction.last_workspace = out["workspace"]
+        return out["mll"].to(A.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g_a, g_r = ctx.saved_tensors
+        go = gout.to(torch.float64)
+        ga = (g_a * go.reshape(go.shape + (1, 1))).to(ctx.dt[0]) if ctx.needs_input_grad[0] else None
+        gr = (g_r * go.reshape(go.shape + (1,))).to(ctx.dt[1]) if ctx.needs_input_grad[1] else None
+        return ga, gr
+
+
+DenseExactMLLFunction.last_workspace = None
+
+
+def dense_exact_mll(A, r):
+    return DenseExactMLLFunction.apply(A, r)

@@ -88,3 +88,43 @@ def lomb_scargle(t, y, dy, freq, fit_mean=True, center_data=True):
     out = np.stack([ls_oracle.power(t[b].detach().cpu().numpy(), y[b].detach().cpu().numpy(),
                                     None if dy is None else dy[b].detach().cpu().numpy(), f, fit_mean, center_data) for b in range(B)])
     return torch.as_tensor(out, dtype=torch.float64, device=y.device)
+
+
+def mll_dense(A, r, jitter=0.0, need_grad=True, workspace=None):
+    """TEST-ONLY stand-in for ``pgmuvi_amd._hip.mll_dense``: value by a torch Cholesky, gradients by autograd."""
+    batched = A.dim() == 3
+    Ab = A.detach().to(torch.float64).reshape(-1, A.shape[-1], A.shape[-1])
+    rb = r.detach().to(torch.float64).reshape(Ab.shape[0], -1)
+    n = Ab.shape[-1]
+    vals, gas, grs, infos = [], [], [], []
+    for b in range(Ab.shape[0]):
+        a = Ab[b].clone().requires_grad_(True)
+        rr = rb[b].clone().requires_grad_(True)
+        try:
+            with torch.enable_grad():                     # (called from inside an autograd.Function.forward)
+                L = torch.linalg.cholesky(a + jitter * torch.eye(n, dtype=torch.float64))
+                z = torch.linalg.solve_triangular(L, rr.reshape(n, 1), upper=False)
+                val = -0.5 * ((z * z).sum() + 2.0 * torch.log(torch.diagonal(L)).sum() + n * orc.LOG_2PI) / n
+                val.backward()
+            ga = 0.5 * (a.grad + a.grad.T)
+            vals.append(val.detach()); gas.append(ga); grs.append(rr.grad); infos.append(0)
+        except torch.linalg.LinAlgError:              # non-PD
+            vals.append(torch.tensor(float("nan"), dtype=torch.float64)); gas.append(torch.zeros(n, n, dtype=torch.float64))
+            grs.append(torch.zeros(n, dtype=torch.float64)); infos.append(1)
+    out = dict(mll=torch.stack(vals), g_a=torch.stack(gas), g_r=torch.stack(grs), info=torch.tensor(infos, dtype=torch.int32))
+    if not batched:
+        out = {k: t[0] for k, t in out.items()}
+    out = {k: t.to(A.device) for k, t in out.items()}
+    out["workspace"] = ("dense", A.detach().clone(), r.detach().clone())
+    return out
+
+
+def predict_dense(ws, k_star, k_ss, mean_test):
+    """TEST-ONLY stand-in for ``pgmuvi_amd._hip.predict_dense``."""
+    _tag, A, r = ws
+    D = torch.float64
+    L = torch.linalg.cholesky(A.to(D))
+    B = torch.linalg.solve_triangular(L, k_star.detach().to(D), upper=False)
+    z = torch.linalg.solve_triangular(L, r.to(D).reshape(-1, 1), upper=False)
+    m = k_star.shape[1]
+    return mean_test.detach().to(D).expand(m) + (B.T @ z).reshape(-1), k_ss.detach().to(D).expand(m) - (B * B).sum(0)

@@ -109,7 +109,7 @@ def test_out_of_scope_names_import_but_refuse_to_run():
     from pgmuvi_amd.gpytorch.kernels import GridInterpolationKernel, ScaleKernel, RBFKernel, MaternKernel  # noqa: F401
     from pgmuvi_amd.gpytorch.variational import CholeskyVariationalDistribution, VariationalStrategy      # noqa: F401
     with pytest.raises(NotImplementedError):
-        RBFKernel()
+        GridInterpolationKernel(RBFKernel(), grid_size=10)
     with pytest.raises(NotImplementedError):
         g.models.ApproximateGP(None)
     for ctx in (g.settings.max_cg_iterations(10000), g.settings.fast_pred_var(), g.settings.fast_computations(False, False, False)):
