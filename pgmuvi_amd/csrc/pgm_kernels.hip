@@ -135,11 +135,15 @@ __device__ __forceinline__ double sm_pair(const double* rowd, const double* cold
 // with the identity.  One workgroup per 128x128 tile; a wave stores one full row
 // (1 KiB) per instruction.
 // ---------------------------------------------------------------------------
+constexpr int BUILD_SPLIT_1D = 4;
 template <int D, int ORDER>
 __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   const int b = blockIdx.z;
   int ib, jb;
-  tri_decode(blockIdx.x, ib, jb);
+  // (1-D: a workgroup builds a quarter of a tile, 32 rows: 2112 workgroups even out over the 256 CUs where 528 did not)
+  constexpr int SPLIT = (D == 1) ? BUILD_SPLIT_1D : 1;
+  const int part = blockIdx.x % SPLIT;
+  tri_decode(blockIdx.x / SPLIT, ib, jb);
   extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD doubles
   double* rowd = sm;
   double* cold = sm + P.pre_slots * NB;
@@ -150,6 +154,45 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   __syncthreads();
   double* A = P.A + b * P.sA;
   const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
+  if (D == 1) {
+    // 1-D: mixtures outermost, the thread's two column factors in registers, its 32 x 2 entries accumulated in
+    // registers: three LDS reads (the row's factors, broadcast) per two entries and mixture instead of nine
+    constexpr int RR = NB / 4 / SPLIT;                     // rows per thread
+    const int row0 = part * (NB / SPLIT);
+    double acc[RR][2];
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) { acc[rr][0] = 0.0; acc[rr][1] = 0.0; }
+    for (int q = 0; q < P.q; ++q) {
+      const double wq = wl[q];
+      const double* cq = cold + q * 3 * NB;
+      const double* rq = rowd + q * 3 * NB;
+      const double cc0 = cq[c2], cc1 = cq[c2 + 1], cs0 = cq[NB + c2], cs1 = cq[NB + c2 + 1];
+      const double cv0 = cq[2 * NB + c2], cv1 = cq[2 * NB + c2 + 1];
+#pragma unroll
+      for (int rr = 0; rr < RR; ++rr) {
+        const int m = row0 + rg + 4 * rr;
+        const double rc = rq[m], rs = rq[NB + m], rv = rq[2 * NB + m];
+        const double d0 = rv - cv0, d1 = rv - cv1;
+        acc[rr][0] = __builtin_fma(wq * exp_neg(-TWO_PI_SQ * d0 * d0), __builtin_fma(rc, cc0, rs * cs0), acc[rr][0]);
+        acc[rr][1] = __builtin_fma(wq * exp_neg(-TWO_PI_SQ * d1 * d1), __builtin_fma(rc, cc1, rs * cs1), acc[rr][1]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int gi = ib * NB + row0 + rg + 4 * rr;
+      v2d out;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int gj = jb * NB + c2 + u;
+        double val = acc[rr][u];
+        if (gi < P.n && gj < P.n) { if (gi == gj) val += P.diagadd[b * P.sVec + gi]; }
+        else val = (gi == gj) ? 1.0 : 0.0;
+        out[u] = val;
+      }
+      *reinterpret_cast<v2d*>(A + (int64_t)gi * P.ld + jb * NB + c2) = out;
+    }
+    return;
+  }
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int m = rg + 4 * rr;
     const int gi = ib * NB + m;
