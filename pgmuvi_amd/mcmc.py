@@ -109,6 +109,7 @@ class SMPotential:
         scale = np.concatenate([np.broadcast_to(s.scale, (B, s.size)) for s in self.sites], axis=1)
         self._loc = torch.as_tensor(loc, dtype=torch.float64, device=self.device)
         self._scale = torch.as_tensor(scale, dtype=torch.float64, device=self.device)
+        self._loc_h, self._scale_h = np.array(loc, dtype=float), np.array(scale, dtype=float)
         self.evaluations = 0
 
     # ---- coordinates ---------------------------------------------------------------------
@@ -141,32 +142,39 @@ class SMPotential:
 
     # ---- the evaluation --------------------------------------------------------------------
     def __call__(self, z: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-        """(B,P) host array -> (U (B,), dU/dz (B,P)); one batched device evaluation, one synchronisation."""
+        """(B,P) host array -> (U (B,), dU/dz (B,P)); one batched device evaluation, one synchronisation.
+
+        The transforms, the chain rule back to z and the prior terms are O(B P) and run on the host in numpy; the
+        device sees one upload (the constrained parameters, packed), the fused evaluation, one packing of its outputs
+        and one download -- a tick is latency-bound, and every small device op it does not issue is ~10 us saved."""
         B, Q, d, N = self.B, self.Q, self.d, self.N
-        zt = torch.as_tensor(np.ascontiguousarray(z), dtype=torch.float64).to(self.device)
-        c = zt[:, 0]
-        w = torch.exp(zt[:, 1:1 + Q])
-        mu = torch.exp(zt[:, 1 + Q:1 + Q + Q * d]).reshape(B, Q, d)
-        v = torch.exp(zt[:, 1 + Q + Q * d:1 + Q + 2 * Q * d]).reshape(B, Q, d)
-        ns = torch.exp(zt[:, 1 + Q + 2 * Q * d]) if self.noise is None else None
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        theta = z.copy()
+        theta[:, 1:] = np.exp(z[:, 1:])                                 # every site but the mean is sampled as a logarithm
+        tt = torch.from_numpy(theta).to(self.device)
+        c = tt[:, 0]
+        w = tt[:, 1:1 + Q]
+        mu = tt[:, 1 + Q:1 + Q + Q * d].reshape(B, Q, d)
+        v = tt[:, 1 + Q + Q * d:1 + Q + 2 * Q * d].reshape(B, Q, d)
+        ns = tt[:, 1 + Q + 2 * Q * d] if self.noise is None else None
         out = self._compute(self.x, self.y, c[:, None].expand(B, N), self.noise, ns, w, mu, v, self.dim_order, 0.0, True)
         self.evaluations += B
-        gl = torch.empty_like(zt)
-        gl[:, 0] = out["g_mean"].sum(-1)
-        gl[:, 1:1 + Q] = out["g_w"] * w
-        gl[:, 1 + Q:1 + Q + Q * d] = (out["g_mu"] * mu).reshape(B, Q * d)
-        gl[:, 1 + Q + Q * d:1 + Q + 2 * Q * d] = (out["g_v"] * v).reshape(B, Q * d)
+        parts = [out["mll"].reshape(B, 1), out["info"].reshape(B, 1).to(torch.float64), out["g_mean"].sum(-1, keepdim=True),
+                 out["g_w"].reshape(B, Q), out["g_mu"].reshape(B, Q * d), out["g_v"].reshape(B, Q * d)]
         if ns is not None:
-            gl[:, -1] = out["g_noise"].sum(-1) * ns
-        t = (zt - self._loc) / self._scale
-        lp = (-0.5 * t * t - torch.log(self._scale) - 0.5 * _LOG_2PI).sum(-1)
-        U = -(N * out["mll"] + lp)
-        g = -(N * gl - t / self._scale)
-        bad = (out["info"] != 0) | ~torch.isfinite(U)
-        U = torch.where(bad, torch.full_like(U, float("inf")), U)
-        g = torch.where(bad[:, None], torch.zeros_like(g), g)
-        host = torch.cat([U[:, None], g], dim=1).cpu().numpy()
-        return host[:, 0], host[:, 1:]
+            parts.append(out["g_noise"].sum(-1, keepdim=True))
+        host = torch.cat(parts, dim=1).cpu().numpy()                     # the tick's one synchronisation
+        mll, info, gtheta = host[:, 0], host[:, 1], host[:, 2:]
+        gl = gtheta.copy()
+        gl[:, 1:] *= theta[:, 1:]                                       # d/dz = theta d/dtheta for the log sites
+        t = (z - self._loc_h) / self._scale_h
+        lp = (-0.5 * t * t - np.log(self._scale_h) - 0.5 * _LOG_2PI).sum(-1)
+        U = -(N * mll + lp)
+        g = -(N * gl - t / self._scale_h)
+        bad = (info != 0) | ~np.isfinite(U)
+        U = np.where(bad, np.inf, U)
+        g = np.where(bad[:, None], 0.0, g)
+        return U, g
 
 
 # --------------------------------------------------------------------------------------------
