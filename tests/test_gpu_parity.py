@@ -74,7 +74,7 @@ def test_golden_fixtures(dev, golden_dir, name):
 
 
 # (1500, 2900: ragged sizes in the fused sweep, where update tiles ride in all three launch kinds of the chain)
-@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 255, 257, 640, 1500, 2900])
+@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 255, 257, 383, 500, 640, 900, 1100, 1300, 1500, 2900])
 def test_ragged_sizes_vs_oracle(dev, n):
     gen = torch.Generator().manual_seed(n)
     x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 500)[0]
