@@ -418,11 +418,11 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
 }
 
 // Filler role of the fused diagonal-block launch.  While workgroup 0 factors block k on one CU
-// (a ~28 us latency-bound chain) the other 255 CUs would idle; instead the same launch carries
-// the trailing update with the previous block row (fill_k = k-1) for every block row >= fill_lo
-// = k+1 -- work that neither this diagonal block nor the following row solve depends on.  A
-// filler workgroup is the same 16 wavefronts as the factoring one and multiplies one 128x128
-// tile at a time, a 32x32 sub-tile per wavefront.
+// (a ~26 us latency-bound chain) the other 255 CUs would idle; instead the same launch carries
+// trailing-update tiles of later block rows (the rows and sources the host's plan selects, below) --
+// work that neither this diagonal block nor the following row solve depends on.  A filler
+// workgroup is the same 16 wavefronts as the factoring one and multiplies one 128x128 tile at a
+// time, a 32x32 sub-tile per wavefront.
 #ifndef PGM_FILL_PF
 #define PGM_FILL_PF 1            // deeper register prefetch (2, 4) measured: no change, the filler loop is not latency-bound
 #endif
