@@ -48,7 +48,7 @@ struct pgm_ws {
   int* info;
   int4* items;           // device copy of the work-item table
   std::vector<int4> items_host;
-  int items_nb, items_count, items_cap, items_kc;
+  int items_nb, items_batch, items_count, items_cap, items_kc;
   // state of the last need_grad evaluation (for pgm_predict_f64)
   PgmDev last;
   bool last_valid;
