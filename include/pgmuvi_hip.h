@@ -129,6 +129,25 @@ const char* pgm_profile_phase_name(int phase);
 int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
 
 /*
+ * Device-resident fit: the optimiser loop of pgmuvi/trainers.py:177-195 for a
+ * constant-mean spectral-mixture exact GP, one hipGraph replay per iteration and no host work in between.
+ * Raw parameter vector (P = 1 + q + 2 q d (+1)): [mean constant | w | mu | v | (learned scalar noise)], each entry with a
+ * GPyTorch constraint: ckind 0 none, 1 softplus(raw) + ca (Positive / GreaterThan), 2 ca - softplus(-raw) (LessThan),
+ * 3 ca + cb * sigmoid(raw) (Interval: ca = lower bound, cb = upper - lower).  optimizer 0 SGD, 1 Adam, 2 AdamW (torch
+ * semantics).  x, y, noise are device pointers that must outlive the handle; raw0 / ckind / ca / cb are host arrays.
+ * pgm_fit_run enqueues `iters` more iterations; pgm_fit_read synchronises and returns the iterations done, the loss
+ * -mll per iteration, the raw parameters after each step ([iters][P]), the current raw parameters and the last
+ * factorisation status.
+ */
+typedef struct pgm_fit pgm_fit;
+int pgm_fit_create(pgm_fit** out, pgm_ws* ws, const double* x, const double* y, const double* noise, int64_t n, int d, int q,
+                   int dim_order, const double* raw0, const int* ckind, const double* ca, const double* cb, int has_noise_param,
+                   int optimizer, double lr, double beta1, double beta2, double eps, double weight_decay, int max_iter);
+int pgm_fit_run(pgm_fit* fit, int iters, void* stream);
+int pgm_fit_read(pgm_fit* fit, void* stream, int* iters_done, double* loss_hist, double* raw_hist, double* raw, int* info);
+int pgm_fit_destroy(pgm_fit* fit);
+
+/*
  * Dense back-end (the reference's non-spectral-mixture models, pgmuvi/gps.py:915-1342:
  * quasi-periodic, Matern, RBF, RQ, separable products, sums): the caller supplies a = K + noise as a dense symmetric
  * matrix ([batch][n][lda], device) and r = y - mean ([batch][n]); mll[batch] is the per-datum log marginal likelihood

@@ -43,6 +43,11 @@ SYMBOLS = {
     "pgm_mll_dense_f64": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p]),
     "pgm_predict_dense_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "pgm_fit_create": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_int]),
+    "pgm_fit_run": (c_int, [c_void_p, c_int, c_void_p]),
+    "pgm_fit_read": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
+    "pgm_fit_destroy": (c_int, [c_void_p]),
     "pgm_lomb_scargle_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p]),
 }
@@ -337,3 +342,63 @@ def predict_dense(ws: Workspace, k_star: torch.Tensor, k_ss: torch.Tensor, mean_
         rc = load().pgm_predict_dense_f64(ws.handle, _ptr(ks), m, _ptr(kss), _ptr(mt), m, _ptr(pm), _ptr(pv), current_stream_ptr(dev))
     _check(rc, "pgm_predict_dense_f64")
     return pm, pv
+
+
+class NativeFit:
+    """Handle of a device-resident fit (``pgm_fit_*``): the optimiser loop of a constant-mean spectral-mixture exact GP as
+    one hipGraph replay per iteration.  ``x`` (n,d), ``y`` (n), ``noise`` (n)|None are kept alive here."""
+
+    OPT = {"SGD": 0, "Adam": 1, "AdamW": 2}
+
+    def __init__(self, x, y, noise, q, dim_order, raw0, ckind, ca, cb, has_noise_param, optimizer, lr, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, max_iter=100, workspace: Optional[Workspace] = None):
+        import numpy as np
+        require_gpu(y, "NativeFit")
+        dev = y.device
+        n = y.shape[-1]
+        self.x = _dev64(x.reshape(n, -1), dev)
+        self.y = _dev64(y.reshape(n), dev)
+        self.noise = None if noise is None else _dev64(noise.expand(n).reshape(n), dev)
+        d = self.x.shape[-1]
+        self.P = len(raw0)
+        self.max_iter = int(max_iter)
+        self.ws = workspace or get_workspace(dev, n, q, d, 1)
+        self.dev = dev
+        arr = lambda a, t: np.ascontiguousarray(np.asarray(a, dtype=t))
+        r0, ck, a_, b_ = arr(raw0, np.float64), arr(ckind, np.int32), arr(ca, np.float64), arr(cb, np.float64)
+        h = c_void_p()
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            rc = load().pgm_fit_create(byref(h), self.ws.handle, _ptr(self.x), _ptr(self.y), _ptr(self.noise), n, d, q, int(dim_order),
+                                       r0.ctypes.data_as(c_void_p), ck.ctypes.data_as(c_void_p), a_.ctypes.data_as(c_void_p),
+                                       b_.ctypes.data_as(c_void_p), 1 if has_noise_param else 0, self.OPT[optimizer], float(lr),
+                                       float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.max_iter)
+        _check(rc, "pgm_fit_create")
+        self.handle = h
+
+    def run(self, iters: int):
+        with torch.cuda.device(self.dev):
+            _check(load().pgm_fit_run(self.handle, int(iters), current_stream_ptr(self.dev)), "pgm_fit_run")
+
+    def read(self):
+        """Synchronises; returns (iterations done, losses (it,), raw parameters after each step (it,P), current raw (P,), info)."""
+        import numpy as np
+        it, info = c_int(), c_int()
+        loss = np.zeros(self.max_iter); hist = np.zeros((self.max_iter, self.P)); raw = np.zeros(self.P)
+        with torch.cuda.device(self.dev):
+            rc = load().pgm_fit_read(self.handle, current_stream_ptr(self.dev), byref(it), loss.ctypes.data_as(c_void_p),
+                                     hist.ctypes.data_as(c_void_p), raw.ctypes.data_as(c_void_p), byref(info))
+        _check(rc, "pgm_fit_read")
+        k = int(it.value)
+        return k, loss[:k], hist[:k], raw, int(info.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().pgm_fit_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

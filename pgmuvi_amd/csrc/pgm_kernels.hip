@@ -1388,6 +1388,110 @@ __global__ __launch_bounds__(256) void k_pred_in(PgmDev P, const double* __restr
   Ks[(int64_t)gi * Mp + gj] = (gi < P.n && gj < M) ? Kin[(int64_t)gi * ldk + gj] : 0.0;
 }
 
+// ---------------------------------------------------------------------------
+// Device-resident fit: one optimiser iteration of pgmuvi/trainers.py:177-195 --
+// constraint transforms, the evaluation above, the chain rule back to the raw parameters, the SGD / Adam / AdamW
+// update, the loss and parameter log -- is two small kernels around the evaluation's launch sequence, all of it one
+// hipGraph replayed per iteration with no host work in between.  Raw parameter vector (P entries):
+//   [ mean constant | w (Q) | mu (Q d) | v (Q d) | (learned scalar noise) ].
+// ---------------------------------------------------------------------------
+struct FitDev {
+  int P, n, q, qd, has_noise, optimizer, max_iter;      // optimizer: 0 SGD, 1 Adam, 2 AdamW
+  double lr, beta1, beta2, eps, weight_decay;
+  double* raw;          // [P] in/out
+  const int* ckind;     // [P] 0 none, 1 softplus + lb, 2 ub - softplus(-raw), 3 lb + span sigmoid(raw)
+  const double* ca;     // [P] lb (kinds 1, 3) or ub (kind 2)
+  const double* cb;     // [P] span (kind 3)
+  double* theta;        // [P] constrained values of this iteration
+  double* mean_vec;     // [n]
+  double* noise_scalar; // [1]
+  double* m1;           // [P] Adam first moment
+  double* m2;           // [P] Adam second moment
+  int* it;              // [1] iterations done so far
+  double* loss_hist;    // [max_iter]
+  double* raw_hist;     // [max_iter][P] raw parameters after each step
+};
+
+__device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+__global__ __launch_bounds__(256) void k_fit_pre(FitDev F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double cval;
+  if (threadIdx.x < F.P && blockIdx.x == 0) {
+    const int p = threadIdx.x;
+    const double r = F.raw[p];
+    double th = r;
+    if (F.ckind[p] == 1) th = softplus_d(r) + F.ca[p];
+    else if (F.ckind[p] == 2) th = F.ca[p] - softplus_d(-r);
+    else if (F.ckind[p] == 3) th = sigmoid_d(r) * F.cb[p] + F.ca[p];
+    F.theta[p] = th;
+    if (F.has_noise && p == F.P - 1) F.noise_scalar[0] = th;
+  }
+  // every workgroup needs the mean constant: recompute it locally instead of waiting for workgroup 0
+  if (threadIdx.x == 0) {
+    const double r = F.raw[0];
+    double th = r;
+    if (F.ckind[0] == 1) th = softplus_d(r) + F.ca[0];
+    else if (F.ckind[0] == 2) th = F.ca[0] - softplus_d(-r);
+    else if (F.ckind[0] == 3) th = sigmoid_d(r) * F.cb[0] + F.ca[0];
+    cval = th;
+  }
+  __syncthreads();
+  if (i < F.n) F.mean_vec[i] = cval;
+}
+
+// after the evaluation: loss, gradients w.r.t. the raw parameters, optimiser step, log.  One workgroup.
+__global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __restrict__ mll, const double* __restrict__ g_w,
+                                                  const double* __restrict__ g_mu, const double* __restrict__ g_v,
+                                                  const double* __restrict__ g_noise, const double* __restrict__ g_mean) {
+  __shared__ double red[256], sums[2];
+  const int t = threadIdx.x;
+  for (int which = 0; which < 2; ++which) {                 // sum of dmll/dmean_i and of dmll/dnoise_i
+    const double* src = which ? g_noise : g_mean;
+    double s = 0.0;
+    if (which == 0 || F.has_noise) for (int i = t; i < F.n; i += 256) s += src[i];
+    red[t] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
+    if (t == 0) sums[which] = red[0];
+    __syncthreads();
+  }
+  const int it = F.it[0];
+  if (t < F.P && it < F.max_iter) {
+    const int p = t;
+    double gth;                                             // d(-mll)/d theta_p
+    if (p == 0) gth = -sums[0];
+    else if (p < 1 + F.q) gth = -g_w[p - 1];
+    else if (p < 1 + F.q + F.qd) gth = -g_mu[p - 1 - F.q];
+    else if (p < 1 + F.q + 2 * F.qd) gth = -g_v[p - 1 - F.q - F.qd];
+    else gth = -sums[1];
+    const double r = F.raw[p];
+    double dth = 1.0;                                       // d theta / d raw
+    if (F.ckind[p] == 1) dth = sigmoid_d(r);
+    else if (F.ckind[p] == 2) dth = sigmoid_d(-r);
+    else if (F.ckind[p] == 3) { const double sg = sigmoid_d(r); dth = F.cb[p] * sg * (1.0 - sg); }
+    const double g = gth * dth;
+    double x = r;
+    if (F.optimizer == 0) {
+      x = r - F.lr * g;
+    } else {
+      if (F.optimizer == 2) x = r * (1.0 - F.lr * F.weight_decay);
+      const double a = F.beta1 * F.m1[p] + (1.0 - F.beta1) * g;
+      const double v2 = F.beta2 * F.m2[p] + (1.0 - F.beta2) * g * g;
+      F.m1[p] = a; F.m2[p] = v2;
+      const double step = (double)(it + 1);
+      const double bc1 = 1.0 - pow(F.beta1, step), bc2 = 1.0 - pow(F.beta2, step);
+      x -= (F.lr / bc1) * a / (sqrt(v2) / sqrt(bc2) + F.eps);
+    }
+    F.raw[p] = x;
+    F.raw_hist[(int64_t)it * F.P + p] = x;
+  }
+  if (t == 0 && it < F.max_iter) F.loss_hist[it] = -mll[0];
+  __syncthreads();
+  if (t == 0) F.it[0] = it + 1;
+}
+
 }  // namespace
 
 // ===========================================================================

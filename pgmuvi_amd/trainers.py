@@ -224,3 +224,130 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
             for n in names:
                 results[n] = list(par_hist[n][:n_done].cpu().numpy())
     return results
+
+
+def _constraint_descriptor(module, raw_name, numel):
+    """(kind, a, b) per element of a raw parameter for pgm_fit_create: GPyTorch's transforms with the bounds as the
+    shim stores them (float32 tensors; an Interval's width is formed in float32, like ``Interval.transform``)."""
+    from .gpytorch import constraints as C
+    c = module._constraints.get(raw_name + "_constraint")
+    if c is None or not c.enforced:
+        return [(0, 0.0, 0.0)] * numel
+    lb = c.lower_bound.detach().cpu().reshape(-1)
+    ub = c.upper_bound.detach().cpu().reshape(-1)
+    if lb.numel() not in (1, numel) or ub.numel() not in (1, numel):
+        raise NotImplementedError("constraint bounds must be scalars or match the parameter")
+    out = []
+    for i in range(numel):
+        l, u = lb[i % lb.numel()], ub[i % ub.numel()]
+        if isinstance(c, C.LessThan):
+            out.append((2, float(u), 0.0))
+        elif isinstance(c, C.GreaterThan):                       # Positive is GreaterThan(0)
+            out.append((1, float(l), 0.0))
+        else:
+            out.append((3, float(l), float(u - l)))
+    return out
+
+
+def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10, stop=None,
+                 lr=1e-4, lossfn="mll", optim="SGD", eps=1e-8, stopavg=9, check_every=25, **kwargs):
+    """:func:`train` with the whole optimiser loop on the device (``pgm_fit_*``): constraint
+    transforms, evaluation, chain rule, SGD / Adam / AdamW step and the loss / parameter log are one hipGraph replay per
+    iteration; the host only reads the log every ``check_every`` iterations for the stop rule of ``pgmuvi/trainers.py:200-207``.
+    For constant-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood; anything
+    else raises ``NotImplementedError`` (use :func:`train_device`).  Same ``results`` as :func:`train`; the model's raw
+    parameters hold the final values afterwards."""
+    from . import _hip
+    from .gpytorch import kernels, likelihoods, means
+    from .gpytorch.utils.errors import NanError
+    if lightcurve is not None:
+        model, likelihood = lightcurve.model, lightcurve.likelihood
+        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
+    elif any(v is None for v in (model, likelihood, train_x, train_y)):
+        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
+                         "and train_y **must** be passed to train().")
+    if lossfn != "mll":
+        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
+    if optim not in _hip.NativeFit.OPT:
+        raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the native loop.")
+    k = getattr(model, "covar_module", None)
+    mm = getattr(model, "mean_module", None)
+    if not isinstance(k, kernels.SpectralMixtureKernel) or type(mm) is not means.ConstantMean:
+        raise NotImplementedError("train_native handles ConstantMean + SpectralMixtureKernel models; use train_device")
+    if any(True for _ in model.named_priors()):
+        raise NotImplementedError("train_native does not add prior terms; use train_device")
+    model.train(); likelihood.train()
+    Q, d = k.num_mixtures, k.ard_num_dims
+    if isinstance(likelihood, likelihoods.FixedNoiseGaussianLikelihood):
+        if getattr(likelihood, "second_noise_covar", None) is not None:
+            raise NotImplementedError("learn_additional_noise is not handled by train_native; use train_device")
+        noise, noise_mod = likelihood.noise.detach(), None
+    elif isinstance(likelihood, likelihoods.GaussianLikelihood):
+        noise, noise_mod = None, likelihood.noise_covar
+    else:
+        raise NotImplementedError("train_native needs a (FixedNoise)GaussianLikelihood")
+    n = train_y.shape[-1]
+    if noise is not None and noise.numel() != n:
+        raise NotImplementedError("the fixed noise must have one entry per training point")
+    # raw vector [c | w | mu | v | (noise)] in the order of the C ABI, and where each piece lives in the model
+    pieces = [(mm, "raw_constant"), (k, "raw_mixture_weights"), (k, "raw_mixture_means"), (k, "raw_mixture_scales")]
+    if noise_mod is not None:
+        pieces.append((noise_mod, "raw_noise"))
+    raw0, desc = [], []
+    for mod, name in pieces:
+        p = getattr(mod, name)
+        raw0.extend(p.detach().double().cpu().reshape(-1).tolist())
+        desc.extend(_constraint_descriptor(mod, name, p.numel()))
+    wd = 0.01 if optim == "AdamW" else 0.0                      # torch's defaults, as trainers.py:147-151 constructs them
+    fit = _hip.NativeFit(train_x, train_y, noise, Q, k.dim_order, raw0, [t[0] for t in desc], [t[1] for t in desc],
+                         [t[2] for t in desc], noise_mod is not None, optim, lr, (0.9, 0.999), eps, wd, maxiter)
+    results = {"loss": [], "delta_loss": []}
+    names = [n_ for n_, _ in model.named_parameters()]
+    if lightcurve is not None:
+        for key, value in lightcurve.get_parameters().items():
+            results[key] = [value.cpu().detach().numpy()]
+    else:
+        for n_ in names:
+            results[n_.split(".")[1] if "raw" in n_ else n_] = []
+            results.setdefault(n_, [])
+    done, stopped = 0, False
+    try:
+        while done < maxiter and not stopped:
+            blk = min(check_every, maxiter - done)
+            fit.run(blk)
+            k_done, losses, hist, raw, info = fit.read()
+            new = losses[done:k_done]
+            if info != 0 or not np.isfinite(new).all():
+                raise NanError("non-finite loss in the native loop (factorisation failed or NaN parameters)")
+            for off, value in enumerate(new):
+                i = done + off
+                if i > 0:
+                    results["delta_loss"].append(value - results["loss"][-1])
+                results["loss"].append(value)
+                if stop and i > miniter and np.std(results["loss"][-stopavg:]) < stop:
+                    print(f"Average change in loss over the last {stopavg} iterations was "
+                          f"{np.std(results['loss'][-stopavg:])}.\n This is < {stop}, so we will end training here.")
+                    stopped = True
+                    break
+            done = k_done
+        n_keep = len(results["loss"])
+        final = hist[n_keep - 1] if n_keep > 0 else np.asarray(raw0)
+        # write the parameters of the last logged iteration back into the model, and the per-iteration history
+        off = 0
+        offsets = {}
+        for mod, name in pieces:
+            p = getattr(mod, name)
+            with torch.no_grad():
+                p.copy_(torch.as_tensor(final[off:off + p.numel()], dtype=p.dtype).reshape(p.shape).to(p.device))
+            offsets[id(p)] = (off, p.numel(), tuple(p.shape))
+            off += p.numel()
+        if lightcurve is None:
+            for n_, p in model.named_parameters():
+                o, cnt, shp = offsets[id(p)]
+                results[n_].extend([hist[i, o:o + cnt].reshape(shp).copy() for i in range(n_keep)])
+        else:
+            for key, value in lightcurve.get_parameters().items():
+                results[key].append(value.cpu().detach().numpy())
+    finally:
+        fit.close()
+    return results

@@ -627,3 +627,61 @@ def test_dense_backend_vs_oracle(dev):
         kss = torch.diagonal(m.covar_module(xs.to(dev)).to_dense()).cpu()
     pm, pv = orc.posterior_dense(Kxx, Kxs, kss, yy, m.mean_module.constant.detach().cpu(), nz, m.mean_module.constant.detach().cpu())
     assert torch.allclose(pred.mean.cpu(), pm, atol=1e-8) and torch.allclose(pred.variance.cpu(), pv, atol=1e-8)
+
+
+def test_native_fit_loop_equals_the_host_loop(dev):
+    """SURVEY.md section 8f row 2, all on the device (pgm_fit_*): transforms, evaluation, chain rule, optimiser step and log
+    as one hipGraph replay per iteration follow the trajectory of the reference-shaped ``train`` (torch optimisers, autograd
+    through the shim's constraints) for SGD, Adam and AdamW, with Interval / GreaterThan / Positive constraints, a fixed
+    noise vector and a learned scalar noise, 1-D and 2-D."""
+    from pgmuvi_amd.trainers import train, train_native
+    t, y, e = syn.cfg2(n_obs=300)
+    x, yy, nz = t.double().to(dev), y.double().to(dev), (e.double() ** 2).to(dev)
+    h = syn.cfg_hypers(2, y.double())
+
+    def build(learn_noise):
+        lik = g.likelihoods.GaussianLikelihood().double().to(dev) if learn_noise else g.likelihoods.FixedNoiseGaussianLikelihood(nz)
+        m = _make_model(dev, x, yy, lik, 4)
+        m.mean_module.register_constraint("raw_constant", g.constraints.Interval(float(yy.min()), float(yy.max())))
+        m.covar_module.register_constraint("raw_mixture_means", g.constraints.GreaterThan(1.0 / 3450.0))
+        m.initialize(**{"covar_module.mixture_weights": h["w"].to(dev) * 0.7, "covar_module.mixture_means": h["mu"].to(dev) * 1.02,
+                        "covar_module.mixture_scales": h["v"].to(dev) * 1.5, "mean_module.constant": torch.tensor(0.1, dtype=D, device=dev)})
+        if learn_noise:
+            lik.noise = torch.tensor(0.02, dtype=D, device=dev)
+        return m, lik
+
+    for optim, learn_noise in (("SGD", False), ("Adam", False), ("AdamW", False), ("AdamW", True)):
+        m1, l1 = build(learn_noise); m2, l2 = build(learn_noise)
+        r1 = train(model=m1, likelihood=l1, train_x=x, train_y=yy, maxiter=40, lr=0.01, optim=optim, progress=False)
+        r2 = train_native(model=m2, likelihood=l2, train_x=x, train_y=yy, maxiter=40, lr=0.01, optim=optim, check_every=16)
+        assert len(r2["loss"]) == 40 and len(r2["delta_loss"]) == 39
+        assert np.allclose(np.array(r1["loss"], dtype=float), np.array(r2["loss"], dtype=float), rtol=0, atol=1e-9), (optim, learn_noise)
+        for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert n1 == n2 and torch.allclose(p1, p2, rtol=1e-8, atol=1e-10), (optim, n1)
+        k = "covar_module.raw_mixture_means"
+        assert np.allclose(np.array(r1[k], dtype=float), np.array(r2[k], dtype=float), atol=1e-9)
+    # early stop on the reference's rule; the model ends at the stop iteration's parameters
+    m3, l3 = build(False); m4, l4 = build(False)
+    r3 = train_native(model=m3, likelihood=l3, train_x=x, train_y=yy, maxiter=400, miniter=10, stop=1e-2, lr=1e-5, optim="SGD", check_every=16)
+    r4 = train(model=m4, likelihood=l4, train_x=x, train_y=yy, maxiter=400, miniter=10, stop=1e-2, lr=1e-5, optim="SGD", progress=False)
+    assert len(r3["loss"]) == len(r4["loss"]) < 400
+    for (n1, p1), (n2, p2) in zip(m3.named_parameters(), m4.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=1e-8, atol=1e-10), n1
+    # 2-D
+    X, Y, E = syn.cfg4(n_per_band=40)
+    X, Y, NZ = X.double().to(dev), Y.double().to(dev), (E.double() ** 2).to(dev)
+    h4 = syn.cfg_hypers(4, Y.cpu())
+    def build2():
+        lik = g.likelihoods.FixedNoiseGaussianLikelihood(NZ)
+        m = _make_model(dev, X, Y, lik, 3, d=2)
+        m.initialize(**{"covar_module.mixture_weights": h4["w"].to(dev), "covar_module.mixture_means": h4["mu"].to(dev),
+                        "covar_module.mixture_scales": h4["v"].to(dev)})
+        return m, lik
+    m5, l5 = build2(); m6, l6 = build2()
+    r5 = train(model=m5, likelihood=l5, train_x=X, train_y=Y, maxiter=15, lr=0.01, optim="Adam", progress=False)
+    r6 = train_native(model=m6, likelihood=l6, train_x=X, train_y=Y, maxiter=15, lr=0.01, optim="Adam")
+    assert np.allclose(np.array(r5["loss"], dtype=float), np.array(r6["loss"], dtype=float), rtol=0, atol=1e-9)
+    # outside its scope it says so
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(nz)
+    with pytest.raises(NotImplementedError):
+        train_native(model=_make_model(dev, x, yy, lik, 2, mean="linear"), likelihood=lik, train_x=x, train_y=yy, maxiter=3)

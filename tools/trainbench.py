@@ -60,3 +60,21 @@ for n in (256, 1024, 4096):
     train(model=m3, likelihood=l3, train_x=x, train_y=yy, maxiter=60, lr=0.001, optim="AdamW", progress=False)
     torch.cuda.synchronize(); dt1 = time.perf_counter() - t0
     print(f"n={n}: train_device {dt/60*1e3:.3f} ms/iter incl. capture (train: {dt1/60*1e3:.3f}); max |loss diff| vs train() {d:.2e}; last losses {float(r1['loss'][-1]):.8f} {float(r2['loss'][-1]):.8f}")
+
+from pgmuvi_amd.trainers import train_native
+for n in (89, 256, 1024, 4096):
+    t, y, e = syn.cfg2(n_obs=n)
+    x, yy, nz = t.double().to(dev), y.double().to(dev), (e.double() ** 2).to(dev)
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(nz)
+    class M(g.models.ExactGP):
+        def __init__(s):
+            super().__init__(x, yy, lik); s.mean_module = g.means.ConstantMean(); s.covar_module = g.kernels.SpectralMixtureKernel(num_mixtures=4)
+        def forward(s, xx): return g.distributions.MultivariateNormal(s.mean_module(xx), s.covar_module(xx))
+    m = M().double().to(dev)
+    h = syn.cfg_hypers(2, y.double())
+    m.initialize(**{"covar_module.mixture_weights": h["w"].to(dev), "covar_module.mixture_means": h["mu"].to(dev), "covar_module.mixture_scales": h["v"].to(dev)})
+    train_native(model=m, likelihood=lik, train_x=x, train_y=yy, maxiter=5, lr=0.001, optim="AdamW")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = train_native(model=m, likelihood=lik, train_x=x, train_y=yy, maxiter=200, lr=0.001, optim="AdamW", check_every=50)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"n={n}: train_native {dt/200*1e3:.3f} ms/iter incl. graph capture ({200/dt:.0f} it/s); loss {r['loss'][0]:.6f} -> {r['loss'][-1]:.6f}")
