@@ -192,3 +192,27 @@ def test_fixed_noise_likelihood_semantics():
         g.likelihoods.FixedNoiseGaussianLikelihood(torch.full((5,), 0.1)).second_noise = 0.1
     with pytest.raises(RuntimeError):
         g.models.ExactGP(torch.zeros(3), torch.zeros(3), likelihood=torch.nn.Identity())
+
+
+def test_native_fit_host_side(small):
+    """The constraint descriptors handed to pgm_fit_create (kinds and bounds exactly as the shim's transforms use them) and
+    the scope checks of train_native; the loop itself needs the GPU (tests/test_gpu_parity.py)."""
+    from pgmuvi_amd.trainers import _constraint_descriptor, train_native
+    x, y, noise = small
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise)
+    m = _model(x, y, lik, Q=2)
+    m.mean_module.register_constraint("raw_constant", g.constraints.Interval(-1.5, 2.5))
+    m.covar_module.register_constraint("raw_mixture_means", g.constraints.GreaterThan(1.0 / 3450.0))
+    m.covar_module.register_constraint("raw_mixture_scales", g.constraints.LessThan(0.5))
+    assert _constraint_descriptor(m.mean_module, "raw_constant", 1) == [(3, -1.5, 4.0)]
+    k1, a1, b1 = _constraint_descriptor(m.covar_module, "raw_mixture_means", 2)[1]
+    assert k1 == 1 and a1 == float(torch.tensor(1.0 / 3450.0).float()) and b1 == 0.0          # float32 bound, as stored
+    assert _constraint_descriptor(m.covar_module, "raw_mixture_scales", 2)[0] == (2, 0.5, 0.0)
+    assert _constraint_descriptor(m.covar_module, "raw_mixture_weights", 2) == [(1, 0.0, 0.0)] * 2        # Positive
+    lin = _model(x, y, lik, Q=2, mean="linear")
+    with pytest.raises(NotImplementedError):
+        train_native(model=lin, likelihood=lik, train_x=x, train_y=y, maxiter=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        train_native(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=2)
+    with pytest.raises(ValueError):
+        train_native(model=m, likelihood=lik)
