@@ -685,3 +685,17 @@ def test_native_fit_loop_equals_the_host_loop(dev):
     lik = g.likelihoods.FixedNoiseGaussianLikelihood(nz)
     with pytest.raises(NotImplementedError):
         train_native(model=_make_model(dev, x, yy, lik, 2, mean="linear"), likelihood=lik, train_x=x, train_y=yy, maxiter=3)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_2d_in_the_fused_sweep_vs_oracle(dev, order):
+    """A 2-D light curve of a size that takes the fused sweep (7 block rows), both readings of the product/sum order."""
+    X, Y, E = syn.cfg4(n_per_band=100)
+    X, Y, nz = X.double(), Y.double(), E.double() ** 2
+    h = syn.cfg_hypers(4, Y)
+    w, mu, v = h["w"], h["mu"].reshape(-1, 2), h["v"].reshape(-1, 2)
+    val, gr = orc.mll_value_grad_closed_form(X, Y, h["mean"], nz, w, mu, v, order, 0.0)
+    out = _hip_eval(dev, X, Y, h["mean"], nz, w, mu, v, order)
+    assert int(out["info"]) == 0 and abs(float(out["mll"]) - float(val)) < MLL_TOL
+    for p in ("w", "mu", "v", "noise", "mean"):
+        assert _rel(out[f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
