@@ -34,3 +34,18 @@ n = y.shape[0]
 for order in (0, 1):
     dt = timeit(lambda: _hip.mll_value_grad(x, y, h["mean"].to(dev).expand(n), nz, None, h["w"].to(dev), h["mu"].reshape(-1, 2).to(dev), h["v"].reshape(-1, 2).to(dev), order, 0.0, True), 3)
     print(f"config 4: N={n}, d=2, Q={h['w'].numel()}, dim_order={order}: {dt*1e3:.2f} ms/eval = {1/dt:.1f} evals/s ({n**3/dt/1e12:.1f} TFLOP/s algorithmic)")
+
+# many short light curves (the survey case: thousands of sources with ~100 epochs each), one launch set
+for B, nn in ((2048, 89), (1024, 256)):
+    xs, ys, ns = [], [], []
+    for i in range(8):
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=nn)
+        xs.append(t.double().reshape(-1, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+    rep = B // 8
+    x = torch.stack(xs).repeat(rep, 1, 1).to(dev); y = torch.stack(ys).repeat(rep, 1).to(dev); nz = torch.stack(ns).repeat(rep, 1).to(dev)
+    h = syn.cfg_hypers(3, ys[0])
+    w = h["w"].expand(B, 4).contiguous().to(dev); mu = h["mu"].reshape(1, 4, 1).expand(B, 4, 1).contiguous().to(dev); v = h["v"].reshape(1, 4, 1).expand(B, 4, 1).contiguous().to(dev)
+    m = torch.zeros(B, nn, dtype=D, device=dev)
+    dt = timeit(lambda: _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True), 5)
+    print(f"many short light curves: {B} x N={nn} per launch set: {dt*1e3:.2f} ms = {B/dt:.0f} evals/s")
+    _hip.release_workspaces()
