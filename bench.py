@@ -192,6 +192,15 @@ def main():
                     flops_per_eval=flops / args.steps)
     if launch_mix:
         roofline["avg_launch_us_by_kernel"] = launch_mix
+    # the HBM-bound stage of the path: the kernel build streams the upper block triangle of A out once (8 N^2 / 2 bytes
+    # at tile granularity; it is in fact bound by the Q N^2 / 2 fp64 exp it evaluates)
+    nbk = (n + NB - 1) // NB
+    build_ms, build_launches = prof["sm_build"]
+    build_bytes = 8.0 * NB * NB * (nbk * (nbk + 1) // 2) * B
+    build_gbs = build_bytes * build_launches / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
+    roofline_build = dict(bound="hbm", kernel="k_build (spectral-mixture kernel matrix, upper block triangle)", achieved=round(build_gbs, 1),
+                          peak=8000.0, unit="GB/s", frac=round(build_gbs / 8000.0, 4), avg_launch_us=round(build_ms / max(build_launches, 1) * 1e3, 2),
+                          bytes_per_launch=build_bytes)
     phases = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
 
     result = None
@@ -205,6 +214,7 @@ def main():
                                    f"{B} light curve(s) per GPU per step", "batch_per_gpu": B, "n": n, "q": 4, "d": 1,
                        "parallelism": f"independent light curves per GPU x{world}, all_gather of log-liks per step"},
             "roofline": roofline,
+            "roofline_build": roofline_build,
             "phase_ms_per_step": phases,
         }
     extra = {}
