@@ -131,7 +131,8 @@ int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
 /*
  * Device-resident fit: the optimiser loop of pgmuvi/trainers.py:177-195 for a
  * constant-mean spectral-mixture exact GP, one hipGraph replay per iteration and no host work in between.
- * Raw parameter vector (P = 1 + q + 2 q d (+1)): [mean constant | w | mu | v | (learned scalar noise)], each entry with a
+ * Raw parameter vector (P = nmean + q + 2 q d (+1)): [mean | w | mu | v | (learned scalar noise)] where the mean block is the
+ * constant (nmean = 1) or, with linear_mean, the d weights then the bias (nmean = d + 1); each entry with a
  * GPyTorch constraint: ckind 0 none, 1 softplus(raw) + ca (Positive / GreaterThan), 2 ca - softplus(-raw) (LessThan),
  * 3 ca + cb * sigmoid(raw) (Interval: ca = lower bound, cb = upper - lower).  optimizer 0 SGD, 1 Adam, 2 AdamW (torch
  * semantics).  x, y, noise are device pointers that must outlive the handle; raw0 / ckind / ca / cb are host arrays.
@@ -141,7 +142,7 @@ int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
  */
 typedef struct pgm_fit pgm_fit;
 int pgm_fit_create(pgm_fit** out, pgm_ws* ws, const double* x, const double* y, const double* noise, int64_t n, int d, int q,
-                   int dim_order, const double* raw0, const int* ckind, const double* ca, const double* cb, int has_noise_param,
+                   int dim_order, int linear_mean, const double* raw0, const int* ckind, const double* ca, const double* cb, int has_noise_param,
                    int optimizer, double lr, double beta1, double beta2, double eps, double weight_decay, int max_iter);
 int pgm_fit_run(pgm_fit* fit, int iters, void* stream);
 int pgm_fit_read(pgm_fit* fit, void* stream, int* iters_done, double* loss_hist, double* raw_hist, double* raw, int* info);

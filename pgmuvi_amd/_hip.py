@@ -43,7 +43,7 @@ SYMBOLS = {
     "pgm_mll_dense_f64": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p]),
     "pgm_predict_dense_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "pgm_fit_create": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+    "pgm_fit_create": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_int]),
     "pgm_fit_run": (c_int, [c_void_p, c_int, c_void_p]),
     "pgm_fit_read": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
@@ -351,7 +351,7 @@ class NativeFit:
     OPT = {"SGD": 0, "Adam": 1, "AdamW": 2}
 
     def __init__(self, x, y, noise, q, dim_order, raw0, ckind, ca, cb, has_noise_param, optimizer, lr, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, max_iter=100, workspace: Optional[Workspace] = None):
+                 weight_decay=0.0, max_iter=100, workspace: Optional[Workspace] = None, linear_mean=False):
         import numpy as np
         require_gpu(y, "NativeFit")
         dev = y.device
@@ -370,7 +370,7 @@ class NativeFit:
         with torch.cuda.device(dev):
             torch.cuda.synchronize(dev)
             rc = load().pgm_fit_create(byref(h), self.ws.handle, _ptr(self.x), _ptr(self.y), _ptr(self.noise), n, d, q, int(dim_order),
-                                       r0.ctypes.data_as(c_void_p), ck.ctypes.data_as(c_void_p), a_.ctypes.data_as(c_void_p),
+                                       1 if linear_mean else 0, r0.ctypes.data_as(c_void_p), ck.ctypes.data_as(c_void_p), a_.ctypes.data_as(c_void_p),
                                        b_.ctypes.data_as(c_void_p), 1 if has_noise_param else 0, self.OPT[optimizer], float(lr),
                                        float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.max_iter)
         _check(rc, "pgm_fit_create")

@@ -1393,10 +1393,11 @@ __global__ __launch_bounds__(256) void k_pred_in(PgmDev P, const double* __restr
 // constraint transforms, the evaluation above, the chain rule back to the raw parameters, the SGD / Adam / AdamW
 // update, the loss and parameter log -- is two small kernels around the evaluation's launch sequence, all of it one
 // hipGraph replayed per iteration with no host work in between.  Raw parameter vector (P entries):
-//   [ mean constant | w (Q) | mu (Q d) | v (Q d) | (learned scalar noise) ].
+//   [ mean: constant, or d weights + bias (linear) | w (Q) | mu (Q d) | v (Q d) | (learned scalar noise) ].
 // ---------------------------------------------------------------------------
 struct FitDev {
-  int P, n, q, qd, has_noise, optimizer, max_iter;      // optimizer: 0 SGD, 1 Adam, 2 AdamW
+  int P, n, d, q, qd, nmean, has_noise, optimizer, max_iter;      // nmean: 1 (constant mean) or d+1 (linear); optimizer: 0 SGD, 1 Adam, 2 AdamW
+  const double* x;      // [n][d] (linear mean)
   double lr, beta1, beta2, eps, weight_decay;
   double* raw;          // [P] in/out
   const int* ckind;     // [P] 0 none, 1 softplus + lb, 2 ub - softplus(-raw), 3 lb + span sigmoid(raw)
@@ -1415,42 +1416,45 @@ struct FitDev {
 __device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
+__device__ __forceinline__ double fit_theta(const FitDev& F, int p) {
+  const double r = F.raw[p];
+  if (F.ckind[p] == 1) return softplus_d(r) + F.ca[p];
+  if (F.ckind[p] == 2) return F.ca[p] - softplus_d(-r);
+  if (F.ckind[p] == 3) return sigmoid_d(r) * F.cb[p] + F.ca[p];
+  return r;
+}
+
 __global__ __launch_bounds__(256) void k_fit_pre(FitDev F) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  __shared__ double cval;
+  __shared__ double mpar[PGM_MAX_D + 1];
   if (threadIdx.x < F.P && blockIdx.x == 0) {
     const int p = threadIdx.x;
-    const double r = F.raw[p];
-    double th = r;
-    if (F.ckind[p] == 1) th = softplus_d(r) + F.ca[p];
-    else if (F.ckind[p] == 2) th = F.ca[p] - softplus_d(-r);
-    else if (F.ckind[p] == 3) th = sigmoid_d(r) * F.cb[p] + F.ca[p];
+    const double th = fit_theta(F, p);
     F.theta[p] = th;
     if (F.has_noise && p == F.P - 1) F.noise_scalar[0] = th;
   }
-  // every workgroup needs the mean constant: recompute it locally instead of waiting for workgroup 0
-  if (threadIdx.x == 0) {
-    const double r = F.raw[0];
-    double th = r;
-    if (F.ckind[0] == 1) th = softplus_d(r) + F.ca[0];
-    else if (F.ckind[0] == 2) th = F.ca[0] - softplus_d(-r);
-    else if (F.ckind[0] == 3) th = sigmoid_d(r) * F.cb[0] + F.ca[0];
-    cval = th;
-  }
+  // every workgroup needs the mean's parameters: recomputed locally instead of waiting for workgroup 0
+  if (threadIdx.x < F.nmean) mpar[threadIdx.x] = fit_theta(F, threadIdx.x);
   __syncthreads();
-  if (i < F.n) F.mean_vec[i] = cval;
+  if (i < F.n) {
+    double m = mpar[F.nmean - 1];                           // the constant, or the bias of a linear mean
+    if (F.nmean > 1) for (int dd = 0; dd < F.d; ++dd) m += F.x[(int64_t)i * F.d + dd] * mpar[dd];
+    F.mean_vec[i] = m;
+  }
 }
 
 // after the evaluation: loss, gradients w.r.t. the raw parameters, optimiser step, log.  One workgroup.
 __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __restrict__ mll, const double* __restrict__ g_w,
                                                   const double* __restrict__ g_mu, const double* __restrict__ g_v,
                                                   const double* __restrict__ g_noise, const double* __restrict__ g_mean) {
-  __shared__ double red[256], sums[2];
+  __shared__ double red[256], sums[PGM_MAX_D + 2];
   const int t = threadIdx.x;
-  for (int which = 0; which < 2; ++which) {                 // sum of dmll/dmean_i and of dmll/dnoise_i
-    const double* src = which ? g_noise : g_mean;
+  // sums of dmll/dmean_i (times x_i,dd for the weights of a linear mean) and, last, of dmll/dnoise_i
+  for (int which = 0; which <= F.nmean; ++which) {
     double s = 0.0;
-    if (which == 0 || F.has_noise) for (int i = t; i < F.n; i += 256) s += src[i];
+    if (which == F.nmean) { if (F.has_noise) for (int i = t; i < F.n; i += 256) s += g_noise[i]; }
+    else if (which == F.nmean - 1) { for (int i = t; i < F.n; i += 256) s += g_mean[i]; }
+    else { for (int i = t; i < F.n; i += 256) s += g_mean[i] * F.x[(int64_t)i * F.d + which]; }
     red[t] = s;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
@@ -1459,13 +1463,13 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
   }
   const int it = F.it[0];
   if (t < F.P && it < F.max_iter) {
-    const int p = t;
+    const int p = t, o = F.nmean;
     double gth;                                             // d(-mll)/d theta_p
-    if (p == 0) gth = -sums[0];
-    else if (p < 1 + F.q) gth = -g_w[p - 1];
-    else if (p < 1 + F.q + F.qd) gth = -g_mu[p - 1 - F.q];
-    else if (p < 1 + F.q + 2 * F.qd) gth = -g_v[p - 1 - F.q - F.qd];
-    else gth = -sums[1];
+    if (p < o) gth = -sums[p];
+    else if (p < o + F.q) gth = -g_w[p - o];
+    else if (p < o + F.q + F.qd) gth = -g_mu[p - o - F.q];
+    else if (p < o + F.q + 2 * F.qd) gth = -g_v[p - o - F.q - F.qd];
+    else gth = -sums[F.nmean];
     const double r = F.raw[p];
     double dth = 1.0;                                       // d theta / d raw
     if (F.ckind[p] == 1) dth = sigmoid_d(r);

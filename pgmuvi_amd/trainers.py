@@ -254,7 +254,7 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
     """:func:`train` with the whole optimiser loop on the device (``pgm_fit_*``): constraint
     transforms, evaluation, chain rule, SGD / Adam / AdamW step and the loss / parameter log are one hipGraph replay per
     iteration; the host only reads the log every ``check_every`` iterations for the stop rule of ``pgmuvi/trainers.py:200-207``.
-    For constant-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood; anything
+    For constant- or linear-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood; anything
     else raises ``NotImplementedError`` (use :func:`train_device`).  Same ``results`` as :func:`train`; the model's raw
     parameters hold the final values afterwards."""
     from . import _hip
@@ -272,8 +272,9 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
         raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the native loop.")
     k = getattr(model, "covar_module", None)
     mm = getattr(model, "mean_module", None)
-    if not isinstance(k, kernels.SpectralMixtureKernel) or type(mm) is not means.ConstantMean:
-        raise NotImplementedError("train_native handles ConstantMean + SpectralMixtureKernel models; use train_device")
+    linear = type(mm) is means.LinearMean
+    if not isinstance(k, kernels.SpectralMixtureKernel) or not (type(mm) is means.ConstantMean or (linear and mm.bias is not None)):
+        raise NotImplementedError("train_native handles Constant/LinearMean + SpectralMixtureKernel models; use train_device")
     if any(True for _ in model.named_priors()):
         raise NotImplementedError("train_native does not add prior terms; use train_device")
     model.train(); likelihood.train()
@@ -289,8 +290,9 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
     n = train_y.shape[-1]
     if noise is not None and noise.numel() != n:
         raise NotImplementedError("the fixed noise must have one entry per training point")
-    # raw vector [c | w | mu | v | (noise)] in the order of the C ABI, and where each piece lives in the model
-    pieces = [(mm, "raw_constant"), (k, "raw_mixture_weights"), (k, "raw_mixture_means"), (k, "raw_mixture_scales")]
+    # raw vector [mean | w | mu | v | (noise)] in the order of the C ABI, and where each piece lives in the model
+    pieces = ([(mm, "weights"), (mm, "bias")] if linear else [(mm, "raw_constant")]) + \
+        [(k, "raw_mixture_weights"), (k, "raw_mixture_means"), (k, "raw_mixture_scales")]
     if noise_mod is not None:
         pieces.append((noise_mod, "raw_noise"))
     raw0, desc = [], []
@@ -300,7 +302,7 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
         desc.extend(_constraint_descriptor(mod, name, p.numel()))
     wd = 0.01 if optim == "AdamW" else 0.0                      # torch's defaults, as trainers.py:147-151 constructs them
     fit = _hip.NativeFit(train_x, train_y, noise, Q, k.dim_order, raw0, [t[0] for t in desc], [t[1] for t in desc],
-                         [t[2] for t in desc], noise_mod is not None, optim, lr, (0.9, 0.999), eps, wd, maxiter)
+                         [t[2] for t in desc], noise_mod is not None, optim, lr, (0.9, 0.999), eps, wd, maxiter, linear_mean=linear)
     results = {"loss": [], "delta_loss": []}
     names = [n_ for n_, _ in model.named_parameters()]
     if lightcurve is not None:

@@ -681,10 +681,30 @@ def test_native_fit_loop_equals_the_host_loop(dev):
     r5 = train(model=m5, likelihood=l5, train_x=X, train_y=Y, maxiter=15, lr=0.01, optim="Adam", progress=False)
     r6 = train_native(model=m6, likelihood=l6, train_x=X, train_y=Y, maxiter=15, lr=0.01, optim="Adam")
     assert np.allclose(np.array(r5["loss"], dtype=float), np.array(r6["loss"], dtype=float), rtol=0, atol=1e-9)
+    # linear mean (the "1DLinear" / "2DLinear" models of pgmuvi/gps.py:223-267, 321-371): weights and bias are parameters too
+    for (xx, yv, nv, dd, Qm) in ((x, yy, nz, 1, 2), (X, Y, NZ, 2, 3)):
+        def buildl():
+            torch.manual_seed(5)                                  # LinearMean draws its initial weights
+            lik = g.likelihoods.FixedNoiseGaussianLikelihood(nv)
+            m = _make_model(dev, xx, yv, lik, Qm, d=dd, mean="linear")
+            with torch.no_grad():
+                m.mean_module.weights.mul_(1e-3); m.mean_module.bias.fill_(0.05)
+            hh = syn.cfg_hypers(2 if dd == 1 else 4, yv.cpu())
+            m.initialize(**{"covar_module.mixture_weights": hh["w"][:Qm].to(dev), "covar_module.mixture_means": hh["mu"][:Qm].to(dev),
+                            "covar_module.mixture_scales": hh["v"][:Qm].to(dev)})
+            return m, lik
+        m7, l7 = buildl(); m8, l8 = buildl()
+        r7 = train(model=m7, likelihood=l7, train_x=xx, train_y=yv, maxiter=12, lr=0.005, optim="AdamW", progress=False)
+        r8 = train_native(model=m8, likelihood=l8, train_x=xx, train_y=yv, maxiter=12, lr=0.005, optim="AdamW")
+        assert np.allclose(np.array(r7["loss"], dtype=float), np.array(r8["loss"], dtype=float), rtol=0, atol=1e-9), dd
+        assert torch.allclose(m7.mean_module.weights, m8.mean_module.weights, rtol=1e-8, atol=1e-12)
+        assert torch.allclose(m7.mean_module.bias, m8.mean_module.bias, rtol=1e-8, atol=1e-12)
     # outside its scope it says so
     lik = g.likelihoods.FixedNoiseGaussianLikelihood(nz)
+    pm = _make_model(dev, x, yy, lik, 2)
+    pm.covar_module.register_prior("mixture_means_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_means")
     with pytest.raises(NotImplementedError):
-        train_native(model=_make_model(dev, x, yy, lik, 2, mean="linear"), likelihood=lik, train_x=x, train_y=yy, maxiter=3)
+        train_native(model=pm, likelihood=lik, train_x=x, train_y=yy, maxiter=3)
 
 
 @pytest.mark.parametrize("order", [0, 1])

@@ -209,9 +209,10 @@ def test_native_fit_host_side(small):
     assert k1 == 1 and a1 == float(torch.tensor(1.0 / 3450.0).float()) and b1 == 0.0          # float32 bound, as stored
     assert _constraint_descriptor(m.covar_module, "raw_mixture_scales", 2)[0] == (2, 0.5, 0.0)
     assert _constraint_descriptor(m.covar_module, "raw_mixture_weights", 2) == [(1, 0.0, 0.0)] * 2        # Positive
-    lin = _model(x, y, lik, Q=2, mean="linear")
-    with pytest.raises(NotImplementedError):
-        train_native(model=lin, likelihood=lik, train_x=x, train_y=y, maxiter=2)
+    pri = _model(x, y, lik, Q=2)
+    pri.covar_module.register_prior("mixture_means_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_means")
+    with pytest.raises(NotImplementedError):                     # prior terms: left to train_device
+        train_native(model=pri, likelihood=lik, train_x=x, train_y=y, maxiter=2)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         train_native(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=2)
     with pytest.raises(ValueError):
