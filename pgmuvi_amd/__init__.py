@@ -10,7 +10,7 @@ from . import _hip, gpytorch, synthetic  # noqa: F401
 from .mll_function import sm_exact_mll  # noqa: F401
 from .trainers import train  # noqa: F401
 
-__all__ = ["gpytorch", "install_as_gpytorch", "sm_exact_mll", "train", "synthetic"]
+__all__ = ["gpytorch", "install_as_gpytorch", "install_native_trainer", "sm_exact_mll", "train", "synthetic"]
 
 
 def install_as_gpytorch(force: bool = False):
@@ -29,3 +29,28 @@ def install_as_gpytorch(force: bool = False):
     sys.modules["gpytorch.mlls.marginal_log_likelihood"] = gpytorch.mlls.marginal_log_likelihood
     sys.modules["gpytorch.utils.errors"] = gpytorch.utils.errors
     return gpytorch
+
+
+def install_native_trainer(fallback=None):
+    """Route ``Lightcurve.fit()``'s optimiser loop (``pgmuvi/lightcurve.py:5870-5879`` calls the ``train`` it imported at
+    ``:32``) to the device-resident loop ``pgmuvi_amd.trainers.train_native``; models outside its scope (priors, other
+    kernels, data on the CPU) fall back to ``fallback`` -- by default the loop pgmuvi came with.  Call after
+    ``import pgmuvi.lightcurve``.  Returns the replaced function."""
+    import pgmuvi.lightcurve as lc_mod
+    from . import trainers
+    original = fallback or lc_mod.train
+
+    def train(lightcurve=None, *args, **kwargs):
+        dev_ok = lightcurve is not None and getattr(lightcurve, "_xdata_transformed", None) is not None and \
+            lightcurve._xdata_transformed.is_cuda
+        if dev_ok and not args:
+            try:
+                known = {k: v for k, v in kwargs.items() if k in ("maxiter", "miniter", "stop", "lr", "lossfn", "optim", "eps", "stopavg")}
+                return trainers.train_native(lightcurve, **known)
+            except NotImplementedError:
+                pass
+        return original(lightcurve, *args, **kwargs)
+
+    train.__wrapped__ = original
+    lc_mod.train = train
+    return original

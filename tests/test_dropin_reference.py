@@ -155,3 +155,33 @@ def test_reference_default_fit_seeds_from_lomb_scargle_like_the_notebook():
         print("LS_SEED_OK", f[:2])
     """ % os.path.join(ROOT, "tests", "golden"))
     assert "LS_SEED_OK" in out
+
+
+def test_native_trainer_hook_routes_fit_and_falls_back():
+    """``install_native_trainer`` replaces the ``train`` that ``Lightcurve.fit`` calls; on the CPU (no device data) and for
+    models outside the native loop's scope the reference's own loop still runs."""
+    out = _run("""
+        from pgmuvi.lightcurve import Lightcurve
+        import pgmuvi.lightcurve as lc_mod
+        calls = []
+        orig = pgmuvi_amd.install_native_trainer()
+        assert lc_mod.train.__wrapped__ is orig
+        t, y, e = syn.cfg2(n_obs=40)
+        with mock.patch.object(_hip, "mll_value_grad", ob.mll_value_grad):
+            lc = Lightcurve(t, y, yerr=e, max_samples=None)
+            res = lc.fit(model="1D", num_mixtures=2, periods=[150.0, 67.0], training_iter=4, lr=0.01, stop=None, miniter=1)
+        assert len(res["loss"]) == 4                    # CPU tensors: the fallback (reference loop) ran
+        # device data: the native loop is asked first
+        import pgmuvi_amd.trainers as tr
+        seen = {}
+        def fake_native(lightcurve, **kw):
+            seen.update(kw); return {"loss": [1.0], "delta_loss": []}
+        import types
+        on_device = types.SimpleNamespace(_xdata_transformed=types.SimpleNamespace(is_cuda=True))
+        with mock.patch.object(tr, "train_native", fake_native):
+            pgmuvi_amd.install_native_trainer(fallback=orig)
+            r = lc_mod.train(on_device, maxiter=7, lr=0.1, optim="AdamW", stop=1e-5, miniter=3, stopavg=30)
+        assert r["loss"] == [1.0] and seen["maxiter"] == 7 and seen["optim"] == "AdamW" and seen["stopavg"] == 30
+        print("HOOK_OK")
+    """)
+    assert "HOOK_OK" in out
