@@ -807,20 +807,53 @@ constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);       
 constexpr int EPI_SLOTS = (CfgBig::LDS_DOUBLES - EPI_FIXED) / (2 * NB);             // staged factor rows (of 128) per side
 static_assert(EPI_SLOTS >= 3 * 2 + 2, "epilogue staging needs room for one 2-D mixture");
 
+// ---------------------------------------------------------------------------
+// diag(A^-1)_c = sum_k V[k][c]^2 (column sums of squares of the inverse factor), needed
+// for d mll / d noise_c = (alpha_c^2 - (A^-1)_cc) / 2N.  Memory-bound (reads V once).
+// Work item (jb, sp): column block x row split; partial sums reduced by k_finalize.  The items run as the last
+// nb * AINV_SPLITS workgroups of the k_lauum_grad launch (they are independent of it, and short).
+// ---------------------------------------------------------------------------
+constexpr int AINV_SPLITS = 32;
+__device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, double* red) {
+  const int b = blockIdx.z;
+  const double* A = P.A + b * P.sA;
+  const double* Vjj = P.Dinv + b * P.sDinv + ((int64_t)jb * 2 + 1) * NB * NB;
+  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int nrows = (P.nb - jb) * NB;                      // rows jb*NB .. np-1
+  const int per = ((nrows + AINV_SPLITS - 1) / AINV_SPLITS + 7) / 8 * 8;
+  const int r0 = sp * per, r1 = min(nrows, r0 + per);
+  auto ld = [&](int rr) -> double {
+    return (rr < NB) ? Vjj[rr * NB + c] : A[(int64_t)(jb * NB + rr) * P.ld + jb * NB + c];
+  };
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int rr = r0 + half;
+  for (; rr + 6 < r1; rr += 8) {                           // four independent loads in flight per lane
+    const double v0 = ld(rr), v1 = ld(rr + 2), v2 = ld(rr + 4), v3 = ld(rr + 6);
+    s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
+  }
+  for (; rr < r1; rr += 2) { const double v0 = ld(rr); s0 += v0 * v0; }
+  const double s = (s0 + s1) + (s2 + s3);
+  if (half == 1) red[c] = s;
+  __syncthreads();
+  if (half == 0) P.dpart[b * P.sDpart + (int64_t)sp * P.np + jb * NB + c] = s + red[c];
+}
+
 template <int D, int ORDER>
 __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   using C = CfgBig;
   const int b = blockIdx.z;
   if (P.info[b] != 0) return;
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  // the diag(A^-1) items ride at the end of the grid (placed first they delay the long inverse tiles: +0.04 ms)
+  if ((int)blockIdx.x >= P.nitems) { const int a = (int)blockIdx.x - P.nitems; ainv_diag_item(P, a % P.nb, a / P.nb, lds); return; }
   // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
   // that no single workgroup sets the makespan; the contraction below is linear in the tile
-  const int lb = blockIdx.x;
+  const int lb = (int)blockIdx.x;
   const int4 item = P.items[lb];
   const int i = item.x, j = item.y, p0 = item.z, plen = item.w;
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
-  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   v4d acc[C::TM][C::TN];
   acc_zero<C>(acc);
   gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
@@ -989,38 +1022,6 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   double* part = P.partials + b * P.sPart + (int64_t)lb * P.nslot;
   for (int s = threadIdx.x; s < P.nslot; s += NTHREADS)
     part[s] = wpart[s] + wpart[P.nslot + s] + wpart[2 * P.nslot + s] + wpart[3 * P.nslot + s];
-}
-
-// ---------------------------------------------------------------------------
-// diag(A^-1)_c = sum_k V[k][c]^2 (column sums of squares of the inverse factor), needed
-// for d mll / d noise_c = (alpha_c^2 - (A^-1)_cc) / 2N.  Memory-bound (reads V once).
-// grid (nb, AINV_SPLITS): column block x row split; partial sums reduced by k_finalize.
-// ---------------------------------------------------------------------------
-constexpr int AINV_SPLITS = 32;
-__global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
-  const int b = blockIdx.z, jb = blockIdx.x, sp = blockIdx.y;
-  if (P.info[b] != 0) return;
-  const double* A = P.A + b * P.sA;
-  const double* Vjj = P.Dinv + b * P.sDinv + ((int64_t)jb * 2 + 1) * NB * NB;
-  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-  const int nrows = (P.nb - jb) * NB;                      // rows jb*NB .. np-1
-  const int per = ((nrows + AINV_SPLITS - 1) / AINV_SPLITS + 7) / 8 * 8;
-  const int r0 = sp * per, r1 = min(nrows, r0 + per);
-  auto ld = [&](int rr) -> double {
-    return (rr < NB) ? Vjj[rr * NB + c] : A[(int64_t)(jb * NB + rr) * P.ld + jb * NB + c];
-  };
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int rr = r0 + half;
-  for (; rr + 6 < r1; rr += 8) {                           // four independent loads in flight per lane
-    const double v0 = ld(rr), v1 = ld(rr + 2), v2 = ld(rr + 4), v3 = ld(rr + 6);
-    s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
-  }
-  for (; rr < r1; rr += 2) { const double v0 = ld(rr); s0 += v0 * v0; }
-  const double s = (s0 + s1) + (s2 + s3);
-  __shared__ double red[NB];
-  if (half == 1) red[c] = s;
-  __syncthreads();
-  if (half == 0) P.dpart[b * P.sDpart + (int64_t)sp * P.np + jb * NB + c] = s + red[c];
 }
 
 // ---------------------------------------------------------------------------
