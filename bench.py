@@ -165,6 +165,9 @@ def main():
         trsm_ms, trsm_launches = prof["row_solve"]
         diag_ms, diag_launches = prof["diag_block"]
         flops += trsm_flops(n, need_grad=True) * B * args.steps
+        # (products of the inverse pass that ran as filler workgroups inside these launches count with them)
+        early_products = ws.early_inverse_products()
+        flops += early_products * 2.0 * NB ** 3 * args.steps
         launch_mix = {"k_diag": round((fused_ms + diag_ms) / max(fused_launches + diag_launches, 1) * 1e3, 2),
                       "k_trsm": round(trsm_ms / max(trsm_launches, 1) * 1e3, 2),
                       "k_update_rows": round(upd_ms / max(upd_launches, 1) * 1e3, 2)}
@@ -182,7 +185,7 @@ def main():
         if tot_l:
             traffic = sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot_l
             traffic_src = f"profiles/{PMC_FILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, same workload, earlier run)"
-    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles; k_trsm: row solve + update tiles; "
+    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles incl. early inverse-pass products; k_trsm: row solve + update tiles; "
              "k_update_rows): trailing-update + row-solve tile GEMM"
              if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN"
     roofline = dict(bound="mfma", kernel=kname,
@@ -192,6 +195,7 @@ def main():
                     flops_per_eval=flops / args.steps)
     if launch_mix:
         roofline["avg_launch_us_by_kernel"] = launch_mix
+        roofline["early_inverse_products_per_eval"] = early_products
     # the HBM-bound stage of the path: the kernel build streams the upper block triangle of A out once (8 N^2 / 2 bytes
     # at tile granularity; it is in fact bound by the Q N^2 / 2 fp64 exp it evaluates)
     nbk = (n + NB - 1) // NB

@@ -127,6 +127,10 @@ int pgm_profile_enable(pgm_ws* ws, int on);
 int pgm_profile_phases(void);
 const char* pgm_profile_phase_name(int phase);
 int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
+/* 128^3 tile products of the inverse pass that the last single-light-curve evaluation with gradient ran inside the
+ * factorisation sweep's diagonal-block launches (on CUs those launches would leave idle) instead of in the
+ * inverse/gradient launch; 0 when that does not apply (batches, small or very large N).  For flop accounting. */
+int64_t pgm_profile_early_inverse_products(const pgm_ws* ws);
 
 /*
  * Device-resident fit: the optimiser loop of pgmuvi/trainers.py:177-195 for a

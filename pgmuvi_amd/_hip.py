@@ -39,6 +39,7 @@ SYMBOLS = {
     "pgm_profile_phases": (c_int, []),
     "pgm_profile_phase_name": (c_char_p, [c_int]),
     "pgm_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+    "pgm_profile_early_inverse_products": (c_int64, [c_void_p]),
     "pgm_probe_mfma_f64": (c_int, [c_int, POINTER(c_double)]),
     "pgm_mll_dense_f64": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p]),
@@ -143,6 +144,10 @@ class Workspace:
         cnt = (c_int64 * n)()
         _check(lib.pgm_profile_read(self.handle, ms, cnt), "pgm_profile_read")
         return {lib.pgm_profile_phase_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+    def early_inverse_products(self) -> int:
+        """128^3 products of the inverse pass the last single-curve evaluation ran inside the sweep's launches."""
+        return int(load().pgm_profile_early_inverse_products(self.handle))
 
 
 _workspaces: Dict[tuple, Workspace] = {}

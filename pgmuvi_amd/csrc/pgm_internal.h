@@ -24,7 +24,10 @@ struct PgmDev {
   double* logdet;     // [batch][nb]
   double* partials;   // [batch][nitems][nslot]
   double* dpart;      // [batch][AINV_SPLITS][np]  partial column sums of squares of V
-  const int4* items;  // [nitems] (i, j, first k-block, k-blocks) of the inverse/gradient pass
+  const int4* items;  // [nitems] (i, j, first k-block, k-blocks | flags << 16) of the inverse/gradient pass
+  double* R;          // [np*np]  early part of the A^-1 tiles (negated), formed by filler workgroups of the late
+                      //          diagonal-block launches (one light curve, fused sweep), or null
+  const int4* tasks;  // (i, j, block row p, flags) of those filler workgroups, in launch order
   double* hyp;        // [batch][3*PGM_MAX_QD] copy of (w, mu, v): the in-graph kernels and prediction read this
   double* diagadd;    // [batch][np]  noise_i + scalar noise + jitter
   double* out_small;  // [batch][1 + q + 2*q*d (+pad)]  mll, g_w, g_mu, g_v
@@ -57,10 +60,19 @@ struct pgm_ws {
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
   int bh, bt;            // fused sweep: update-tile budgets of the head and row-solve launches (128x128 tiles)
+  // early inverse pass (fused sweep, one light curve): the late diagonal-block launches have fewer update tiles than
+  // CUs; their spare workgroups form  R_ij = sum_p V_pi^T V_pj  over block rows p that are already final
+  int early;             // 0 = off
+  int early_nb;          // block rows the tables below were made for (-1: none)
+  std::vector<int4> early_host;          // [final work items | filler tasks]
+  std::vector<int> early_lo, early_n;    // filler tasks of diagonal-block launch k: [early_lo[k], +early_n[k]) of the task part
+  int4* early_items;     // device copy
+  int early_cap, early_final_n;
+  double* Rbuf; size_t R_bytes;
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;
-  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; hipGraphExec_t exec; };
+  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; bool early; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
   // profiling
   bool prof_on;

@@ -500,7 +500,27 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
   acc_store<C>(Cp, ld, acc, -1.0);
 }
 
-__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan) {
+// Second filler role of the late diagonal-block launches (one light curve): when the plan leaves CUs without an update
+// tile, they start on the inverse pass -- one product  R_ij += V_pi^T V_pj  of a block row p that is already final, kept
+// negated in R (acc_load_neg reads it back); k_lauum_grad later continues from R instead of from zero.
+constexpr int LAUUM_LOAD = 1 << 16;
+__device__ __forceinline__ void early_inverse_tile(const PgmDev& P, double* lds, const int4 task) {
+  using C = CfgFill;
+  const int i = task.x, j = task.y, p = task.z;
+  const int64_t ld = P.ld;
+  double* Rp = P.R + (int64_t)i * NB * ld + j * NB;
+  const double* pa0 = (p > i) ? P.A + (int64_t)p * NB * ld + i * NB : P.Dinv + ((int64_t)i * 2 + 1) * NB * NB;
+  const double* pb0 = (p > j) ? P.A + (int64_t)p * NB * ld + j * NB : P.Dinv + ((int64_t)j * 2 + 1) * NB * NB;
+  const int64_t lda0 = (p > i) ? ld : NB, ldb0 = (p > j) ? ld : NB;
+  v4d acc[C::TM][C::TN];
+  if (task.w & LAUUM_LOAD) acc_load_neg<C>(Rp, ld, acc); else acc_zero<C>(acc);
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = pa0; lda = lda0; pb = pb0; ldb = ldb0;
+  }, acc);
+  acc_store<C>(Rp, ld, acc, -1.0);
+}
+
+__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan, int nfill, int task_lo) {
   const int b = blockIdx.z;
   // (no early exit on P.info here or in k_trsm / k_update: after a failed pivot the chain kernels just
   //  carry NaNs -- no address depends on data -- and a dependent scalar load in front of every one of the
@@ -515,7 +535,9 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   const long long entry_ = __builtin_amdgcn_s_memtime();
 #endif
   if (blockIdx.x > 0) {
-    plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, (int)blockIdx.x - 1);
+    const int widx = (int)blockIdx.x - 1;
+    if (widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, widx);
+    else early_inverse_tile(P, M, P.tasks[task_lo + widx - nfill]);
     return;
   }
   const int t = threadIdx.x, lane = t & 63;
@@ -850,12 +872,14 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   // that no single workgroup sets the makespan; the contraction below is linear in the tile
   const int lb = (int)blockIdx.x;
   const int4 item = P.items[lb];
-  const int i = item.x, j = item.y, p0 = item.z, plen = item.w;
+  const int i = item.x, j = item.y, p0 = item.z, plen = item.w & 0xffff;
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
   v4d acc[C::TM][C::TN];
-  acc_zero<C>(acc);
+  // (the sum over the block rows before p0 was left in R, negated, by the sweep's spare filler workgroups)
+  if (item.w & LAUUM_LOAD) acc_load_neg<C>(P.R + (int64_t)i * NB * ld + j * NB, ld, acc);
+  else acc_zero<C>(acc);
   gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = p0 + kb;
     if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB; lda = ld; }
@@ -916,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
         const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
         const int gi = i * NB + m, gj = j * NB + n;
         const bool valid = (gi < P.n) && (gj < P.n);
-        const double aa = (p0 == j) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
+        const double aa = (p0 + plen == P.nb) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
         acc[ti][tj][r] = valid ? sym * (aa - acc[ti][tj][r]) : 0.0;
       }
 #pragma unroll 1

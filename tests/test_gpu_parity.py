@@ -719,3 +719,41 @@ def test_2d_in_the_fused_sweep_vs_oracle(dev, order):
     assert int(out["info"]) == 0 and abs(float(out["mll"]) - float(val)) < MLL_TOL
     for p in ("w", "mu", "v", "noise", "mean"):
         assert _rel(out[f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
+@pytest.mark.parametrize("case", ["1d_2900", "2d_order0", "2d_order1"])
+def test_early_inverse_pass_equals_the_plain_schedule(dev, monkeypatch, case):
+    """Single light curves in the fused sweep start the inverse pass inside the late diagonal-block launches (spare
+    workgroups sum V_pi^T V_pj over finished block rows into R).  Same value and gradients as the plain schedule
+    (PGM_EARLY=0: the inverse pass all in its own launch), to rounding of the different summation split, and vs the oracle."""
+    if case == "1d_2900":
+        gen = torch.Generator().manual_seed(5)
+        n = 2900
+        x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 900)[0]
+        y = torch.randn(n, generator=gen, dtype=D)
+        nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+        w = torch.tensor([0.6, 0.3, 0.2], dtype=D); mu = torch.tensor([[0.02], [0.11], [0.3]], dtype=D)
+        v = torch.tensor([[0.003], [0.01], [0.02]], dtype=D)
+        mean, order = 0.1, 0
+    else:
+        X, Y, E = syn.cfg4(n_per_band=170)                     # 8 bands x 170 = 1360 points: 11 block rows
+        x, y, nz = X.double(), Y.double(), E.double() ** 2
+        h = syn.cfg_hypers(4, Y)
+        w, mu, v, mean = h["w"], h["mu"].reshape(-1, 2), h["v"].reshape(-1, 2), h["mean"]
+        order = 1 if case.endswith("1") else 0
+    n, q, d = y.shape[0], w.shape[0], mu.shape[1]
+    outs = {}
+    for flag in ("0", "1"):
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_EARLY", flag)
+        outs[flag] = {k: t.clone() for k, t in _hip_eval(dev, x, y, mean, nz, w, mu, v, order).items() if torch.is_tensor(t)}
+        moved = _hip.get_workspace(dev, n, q, d).early_inverse_products()
+        assert (moved > 0) == (flag == "1"), moved
+    _hip.release_workspaces()
+    assert float(outs["0"]["mll"]) == float(outs["1"]["mll"])
+    for p in ("w", "mu", "v", "noise", "mean"):
+        assert _rel(outs["1"][f"g_{p}"].reshape(-1), outs["0"][f"g_{p}"].reshape(-1)) < 1e-11, p
+    val, gr = orc.mll_value_grad_closed_form(x, y, mean, nz, w, mu, v, order, 0.0)
+    assert abs(float(outs["1"]["mll"]) - float(val)) < MLL_TOL
+    for p in ("w", "mu", "v", "noise", "mean"):
+        assert _rel(outs["1"][f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p

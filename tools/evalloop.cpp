@@ -22,7 +22,11 @@ int main(int argc, char** argv) {
   for (int r = 0; r < reps; ++r) run();
   hipStreamSynchronize(st);
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
-  double h; hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
-  printf("n=%d need_grad=%d: %.3f ms/eval  mll=%.12f\n", n, ng, ms, h);
+  std::vector<double> h(16 + 3 * (size_t)n);
+  hipMemcpy(h.data(), out, 8 * h.size(), hipMemcpyDeviceToHost);
+  double gs = 0.0, gn = 0.0;                                   // gradient fingerprints: hyper-parameters, per-point noise
+  for (int a = 1; a < 1 + 3 * q && ng; ++a) gs += h[(size_t)(a < 1 + q ? a : (a < 1 + 2 * q ? 5 + a - 1 - q : 9 + a - 1 - 2 * q))] * (1.0 + 0.1 * a);
+  for (int i = 0; i < n && ng; ++i) gn += h[16 + (size_t)i] * (1.0 + 1e-3 * (i % 97));
+  printf("n=%d need_grad=%d: %.3f ms/eval  mll=%.12f  gsum=%.12e  gnoise=%.12e\n", n, ng, ms, h[0], gs, gn);
   return 0;
 }
