@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 from pgmuvi_amd import _hip, synthetic as syn  # noqa: E402
 from pgmuvi_amd.batch import gather_logliks  # noqa: E402
 
-PMC_FILE = "r01_pmc_hbm_traffic_v2.json"
+PMC_FILE = "r01_pmc_hbm_traffic_v3.json"
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet "FP64 matrix" (the guides list no fp64 MFMA figure)
 NB = 128
 
