@@ -143,11 +143,16 @@ int64_t pgm_profile_early_inverse_products(const pgm_ws* ws);
  * pgm_fit_run enqueues `iters` more iterations; pgm_fit_read synchronises and returns the iterations done, the loss
  * -mll per iteration, the raw parameters after each step ([iters][P]), the current raw parameters and the last
  * factorisation status.
+ * pgm_fit_set_priors (optional, before the first pgm_fit_run): MAP instead of maximum likelihood -- per raw-vector entry
+ * a prior on the CONSTRAINED value, kind 0 none, 1 Normal(loc, scale), 2 LogNormal(loc, scale) (the priors
+ * pgmuvi/lightcurve.py:3273-3322 registers); their log densities are added to N * mll before the division by N, as
+ * gpytorch's ExactMarginalLogLikelihood does, and the logged loss includes them.  Host arrays of P entries.
  */
 typedef struct pgm_fit pgm_fit;
 int pgm_fit_create(pgm_fit** out, pgm_ws* ws, const double* x, const double* y, const double* noise, int64_t n, int d, int q,
                    int dim_order, int linear_mean, const double* raw0, const int* ckind, const double* ca, const double* cb, int has_noise_param,
                    int optimizer, double lr, double beta1, double beta2, double eps, double weight_decay, int max_iter);
+int pgm_fit_set_priors(pgm_fit* fit, const int* kind, const double* loc, const double* scale);
 int pgm_fit_run(pgm_fit* fit, int iters, void* stream);
 int pgm_fit_read(pgm_fit* fit, void* stream, int* iters_done, double* loss_hist, double* raw_hist, double* raw, int* info);
 int pgm_fit_destroy(pgm_fit* fit);

@@ -46,6 +46,7 @@ SYMBOLS = {
     "pgm_predict_dense_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "pgm_fit_create": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_int]),
+    "pgm_fit_set_priors": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "pgm_fit_run": (c_int, [c_void_p, c_int, c_void_p]),
     "pgm_fit_read": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "pgm_fit_destroy": (c_int, [c_void_p]),
@@ -380,6 +381,17 @@ class NativeFit:
                                        float(betas[0]), float(betas[1]), float(eps), float(weight_decay), self.max_iter)
         _check(rc, "pgm_fit_create")
         self.handle = h
+
+    def set_priors(self, kind, loc, scale):
+        """Priors on the constrained parameters (per raw-vector entry: 0 none, 1 Normal, 2 LogNormal); before the first run."""
+        import numpy as np
+        arr = lambda a, t: np.ascontiguousarray(np.asarray(a, dtype=t))
+        k, l, s = arr(kind, np.int32), arr(loc, np.float64), arr(scale, np.float64)
+        if not (k.shape == l.shape == s.shape == (self.P,)):
+            raise ValueError(f"prior tables must have {self.P} entries")
+        with torch.cuda.device(self.dev):
+            _check(load().pgm_fit_set_priors(self.handle, k.ctypes.data_as(c_void_p), l.ctypes.data_as(c_void_p),
+                                             s.ctypes.data_as(c_void_p)), "pgm_fit_set_priors")
 
     def run(self, iters: int):
         with torch.cuda.device(self.dev):

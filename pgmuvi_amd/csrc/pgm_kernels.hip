@@ -1436,6 +1436,11 @@ struct FitDev {
   int* it;              // [1] iterations done so far
   double* loss_hist;    // [max_iter]
   double* raw_hist;     // [max_iter][P] raw parameters after each step
+  // priors on the constrained parameters (MAP): the reference's ExactMarginalLogLikelihood adds sum log p(theta) before the
+  // division by N (pgmuvi/lightcurve.py:3273-3322 registers Normal and LogNormal priors)
+  const int* pkind;     // [P] 0 none, 1 Normal(loc, scale), 2 LogNormal(loc, scale)
+  const double* ploc;   // [P]
+  const double* pscale; // [P]
 };
 
 __device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }
@@ -1487,6 +1492,25 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
     __syncthreads();
   }
   const int it = F.it[0];
+  // log prior of every parameter and its derivative w.r.t. the constrained value
+  double lp = 0.0, dlp = 0.0;
+  if (t < F.P && F.pkind[t] != 0) {
+    const double th = F.theta[t], mu = F.ploc[t], sg = F.pscale[t];
+    constexpr double HALF_LOG_2PI = 0.91893853320467274178;
+    if (F.pkind[t] == 1) {
+      const double zz = (th - mu) / sg;
+      lp = -0.5 * zz * zz - log(sg) - HALF_LOG_2PI;
+      dlp = -zz / sg;
+    } else {
+      const double lt = log(th), zz = (lt - mu) / sg;
+      lp = -0.5 * zz * zz - log(sg) - HALF_LOG_2PI - lt;
+      dlp = -(1.0 + zz / sg) / th;
+    }
+  }
+  red[t] = lp;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
+  const double lp_sum = red[0];
   if (t < F.P && it < F.max_iter) {
     const int p = t, o = F.nmean;
     double gth;                                             // d(-mll)/d theta_p
@@ -1495,6 +1519,7 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
     else if (p < o + F.q + F.qd) gth = -g_mu[p - o - F.q];
     else if (p < o + F.q + 2 * F.qd) gth = -g_v[p - o - F.q - F.qd];
     else gth = -sums[F.nmean];
+    gth -= dlp / (double)F.n;
     const double r = F.raw[p];
     double dth = 1.0;                                       // d theta / d raw
     if (F.ckind[p] == 1) dth = sigmoid_d(r);
@@ -1516,7 +1541,7 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
     F.raw[p] = x;
     F.raw_hist[(int64_t)it * F.P + p] = x;
   }
-  if (t == 0 && it < F.max_iter) F.loss_hist[it] = -mll[0];
+  if (t == 0 && it < F.max_iter) F.loss_hist[it] = -(mll[0] + lp_sum / (double)F.n);
   __syncthreads();
   if (t == 0) F.it[0] = it + 1;
 }

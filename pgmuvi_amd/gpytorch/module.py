@@ -83,6 +83,7 @@ class Module(nn.Module):
 
             def closure(module, _n=pname):
                 return getattr(module, _n)
+            closure.param_name = pname            # (lets the native fit loop see which parameter a prior is on)
 
             if setting_closure is None:
                 def setting_closure(module, val, _n=pname):

@@ -249,12 +249,51 @@ def _constraint_descriptor(module, raw_name, numel):
     return out
 
 
+def _prior_descriptor(model, likelihood, pieces, noise_mod):
+    """(kind, loc, scale) per entry of the native loop's raw vector from the priors registered on the model and the
+    likelihood -- what ``ExactMarginalLogLikelihood`` would add (``named_priors`` of both, ``log_prob(closure(module)).sum()``).
+    Plain Normal / LogNormal priors on a named parameter of the pieces only; anything else is outside the native loop."""
+    from .gpytorch import priors as PR
+    offsets, off = {}, 0
+    for mod, name in pieces:
+        numel = getattr(mod, name).numel()
+        offsets[(id(mod), name[4:] if name.startswith("raw_") else name)] = (off, numel)
+        off += numel
+    if noise_mod is not None:                                    # ``likelihood.noise`` is the same parameter as ``noise_covar.noise``
+        offsets[(id(likelihood), "noise")] = offsets[(id(noise_mod), "noise")]
+    kind, loc, scale = [0] * off, [0.0] * off, [1.0] * off
+    found, seen = False, set()
+    for owner in (model, likelihood):
+        for pname, module, prior, closure, _ in owner.named_priors():
+            if id(prior) in seen:                                # (the likelihood is also a sub-module of an ExactGP)
+                continue
+            seen.add(id(prior))
+            target = getattr(closure, "param_name", None)
+            key = (id(module), target)
+            if target is None or key not in offsets:
+                raise NotImplementedError(f"prior {pname}: not on a parameter of the native loop; use train_device")
+            if type(prior) not in (PR.NormalPrior, PR.LogNormalPrior) or getattr(prior, "_transform", None) is not None:
+                raise NotImplementedError(f"prior {pname}: only plain Normal / LogNormal priors run in the native loop; use train_device")
+            o, numel = offsets[key]
+            shape = getattr(module, target).shape
+            l = torch.as_tensor(prior.loc).detach().double().cpu().expand(shape).reshape(-1)
+            s_ = torch.as_tensor(prior.scale).detach().double().cpu().expand(shape).reshape(-1)
+            for i in range(numel):
+                if kind[o + i] != 0:
+                    raise NotImplementedError(f"prior {pname}: a second prior on the same parameter; use train_device")
+                kind[o + i] = 1 if type(prior) is PR.NormalPrior else 2
+                loc[o + i], scale[o + i] = float(l[i]), float(s_[i])
+            found = True
+    return (kind, loc, scale) if found else None
+
+
 def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10, stop=None,
                  lr=1e-4, lossfn="mll", optim="SGD", eps=1e-8, stopavg=9, check_every=25, **kwargs):
     """:func:`train` with the whole optimiser loop on the device (``pgm_fit_*``): constraint
     transforms, evaluation, chain rule, SGD / Adam / AdamW step and the loss / parameter log are one hipGraph replay per
     iteration; the host only reads the log every ``check_every`` iterations for the stop rule of ``pgmuvi/trainers.py:200-207``.
-    For constant- or linear-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood; anything
+    For constant- or linear-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood, with or
+    without plain Normal / LogNormal priors on those parameters (MAP, the priors ``set_default_priors`` registers); anything
     else raises ``NotImplementedError`` (use :func:`train_device`).  Same ``results`` as :func:`train`; the model's raw
     parameters hold the final values afterwards."""
     from . import _hip
@@ -275,8 +314,6 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
     linear = type(mm) is means.LinearMean
     if not isinstance(k, kernels.SpectralMixtureKernel) or not (type(mm) is means.ConstantMean or (linear and mm.bias is not None)):
         raise NotImplementedError("train_native handles Constant/LinearMean + SpectralMixtureKernel models; use train_device")
-    if any(True for _ in model.named_priors()):
-        raise NotImplementedError("train_native does not add prior terms; use train_device")
     model.train(); likelihood.train()
     Q, d = k.num_mixtures, k.ard_num_dims
     if isinstance(likelihood, likelihoods.FixedNoiseGaussianLikelihood):
@@ -300,9 +337,12 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
         p = getattr(mod, name)
         raw0.extend(p.detach().double().cpu().reshape(-1).tolist())
         desc.extend(_constraint_descriptor(mod, name, p.numel()))
+    prior_tab = _prior_descriptor(model, likelihood, pieces, noise_mod)
     wd = 0.01 if optim == "AdamW" else 0.0                      # torch's defaults, as trainers.py:147-151 constructs them
     fit = _hip.NativeFit(train_x, train_y, noise, Q, k.dim_order, raw0, [t[0] for t in desc], [t[1] for t in desc],
                          [t[2] for t in desc], noise_mod is not None, optim, lr, (0.9, 0.999), eps, wd, maxiter, linear_mean=linear)
+    if prior_tab is not None:
+        fit.set_priors(*prior_tab)
     results = {"loss": [], "delta_loss": []}
     names = [n_ for n_, _ in model.named_parameters()]
     if lightcurve is not None:

@@ -702,9 +702,52 @@ def test_native_fit_loop_equals_the_host_loop(dev):
     # outside its scope it says so
     lik = g.likelihoods.FixedNoiseGaussianLikelihood(nz)
     pm = _make_model(dev, x, yy, lik, 2)
-    pm.covar_module.register_prior("mixture_means_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_means")
+    pm.covar_module.register_prior("mixture_means_prior", g.priors.UniformPrior(0.0, 1.0), "mixture_means")
     with pytest.raises(NotImplementedError):
         train_native(model=pm, likelihood=lik, train_x=x, train_y=yy, maxiter=3)
+
+
+def test_native_fit_loop_with_the_default_priors(dev):
+    """MAP in the native loop: the priors ``Lightcurve.set_default_priors`` registers (``pgmuvi/lightcurve.py:3273-3322``:
+    Normal on the mean constant, LogNormal(0, 1) on mixture means / scales / weights, LogNormal on a learned noise) are
+    added on the device before the division by N; same trajectory as the reference-shaped ``train`` through the shim's
+    ExactMarginalLogLikelihood, for a fixed-noise and a learned-noise likelihood."""
+    from pgmuvi_amd.trainers import train, train_native
+    t, y, e = syn.cfg2(n_obs=260)
+    x, yy, nz = t.double().to(dev), y.double().to(dev), (e.double() ** 2).to(dev)
+    h = syn.cfg_hypers(2, y.double())
+
+    def build(learn_noise):
+        lik = g.likelihoods.GaussianLikelihood().double().to(dev) if learn_noise else g.likelihoods.FixedNoiseGaussianLikelihood(nz)
+        m = _make_model(dev, x, yy, lik, 3)
+        m.covar_module.register_constraint("raw_mixture_means", g.constraints.GreaterThan(1.0 / 3450.0))
+        m.initialize(**{"covar_module.mixture_weights": h["w"][:3].to(dev) * 0.8, "covar_module.mixture_means": h["mu"][:3].to(dev) * 1.03,
+                        "covar_module.mixture_scales": h["v"][:3].to(dev) * 1.4, "mean_module.constant": torch.tensor(0.05, dtype=D, device=dev)})
+        m.mean_module.register_prior("mean_prior", g.priors.NormalPrior(float(yy.mean()), float(yy.std()) / 10), "constant")
+        m.covar_module.register_prior("mixture_means_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_means")
+        m.covar_module.register_prior("mixture_scales_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_scales")
+        m.covar_module.register_prior("mixture_weights_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_weights")
+        if learn_noise:
+            lik.noise = torch.tensor(0.02, dtype=D, device=dev)
+            lik.noise_covar.register_prior("noise_prior", g.priors.LogNormalPrior(float(np.log(0.02)), 0.5), "noise")
+        return m.double().to(dev), lik
+
+    for optim, learn_noise in (("Adam", False), ("AdamW", True), ("SGD", True)):
+        m1, l1 = build(learn_noise); m2, l2 = build(learn_noise)
+        r1 = train(model=m1, likelihood=l1, train_x=x, train_y=yy, maxiter=30, lr=0.01, optim=optim, progress=False)
+        r2 = train_native(model=m2, likelihood=l2, train_x=x, train_y=yy, maxiter=30, lr=0.01, optim=optim, check_every=8)
+        assert np.allclose(np.array(r1["loss"], dtype=float), np.array(r2["loss"], dtype=float), rtol=0, atol=1e-9), (optim, learn_noise)
+        for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert n1 == n2 and torch.allclose(p1, p2, rtol=1e-8, atol=1e-10), (optim, n1)
+    # and the prior terms are really there: the same model without priors follows a different path
+    m3, l3 = build(False)
+    for mod in (m3.mean_module, m3.covar_module):
+        for name in list(mod._priors):
+            del mod._priors[name]
+    r3 = train_native(model=m3, likelihood=l3, train_x=x, train_y=yy, maxiter=30, lr=0.01, optim="Adam")
+    m4, l4 = build(False)
+    r4 = train_native(model=m4, likelihood=l4, train_x=x, train_y=yy, maxiter=30, lr=0.01, optim="Adam")
+    assert abs(r3["loss"][0] - r4["loss"][0]) > 1e-4
 
 
 @pytest.mark.parametrize("order", [0, 1])

@@ -209,10 +209,29 @@ def test_native_fit_host_side(small):
     assert k1 == 1 and a1 == float(torch.tensor(1.0 / 3450.0).float()) and b1 == 0.0          # float32 bound, as stored
     assert _constraint_descriptor(m.covar_module, "raw_mixture_scales", 2)[0] == (2, 0.5, 0.0)
     assert _constraint_descriptor(m.covar_module, "raw_mixture_weights", 2) == [(1, 0.0, 0.0)] * 2        # Positive
-    pri = _model(x, y, lik, Q=2)
+    # prior tables for pgm_fit_set_priors: plain Normal / LogNormal priors on the loop's parameters, in raw-vector order
+    from pgmuvi_amd.trainers import _prior_descriptor
+    glik = g.likelihoods.GaussianLikelihood()
+    pri = _model(x, y, glik, Q=2)
+    pieces = [(pri.mean_module, "raw_constant"), (pri.covar_module, "raw_mixture_weights"), (pri.covar_module, "raw_mixture_means"),
+              (pri.covar_module, "raw_mixture_scales"), (glik.noise_covar, "raw_noise")]
+    assert _prior_descriptor(pri, glik, pieces, glik.noise_covar) is None
+    pri.mean_module.register_prior("mean_prior", g.priors.NormalPrior(0.3, 0.1), "constant")
     pri.covar_module.register_prior("mixture_means_prior", g.priors.LogNormalPrior(0.0, 1.0), "mixture_means")
-    with pytest.raises(NotImplementedError):                     # prior terms: left to train_device
-        train_native(model=pri, likelihood=lik, train_x=x, train_y=y, maxiter=2)
+    glik.register_prior("noise_prior", g.priors.LogNormalPrior(-4.0, 0.5), "noise")       # on the likelihood, as pgmuvi/test_script.py:235
+    kind, loc, scale = _prior_descriptor(pri, glik, pieces, glik.noise_covar)
+    assert kind == [1, 0, 0, 2, 2, 0, 0, 2]
+    assert loc[0] == pytest.approx(0.3) and scale[0] == pytest.approx(0.1) and loc[7] == -4.0 and scale[7] == 0.5 and loc[3:5] == [0.0, 0.0]
+    pri.covar_module.register_prior("w_prior", g.priors.UniformPrior(0.0, 1.0), "mixture_weights")
+    with pytest.raises(NotImplementedError):                     # other prior families: left to train_device
+        _prior_descriptor(pri, glik, pieces, glik.noise_covar)
+    with pytest.raises(NotImplementedError):
+        train_native(model=pri, likelihood=glik, train_x=x, train_y=y, maxiter=2)
+    fx = _model(x, y, lik, Q=2)
+    lik.register_prior("noise_prior", g.priors.LogNormalPrior(-4.0, 0.5), "noise")         # a prior on a FIXED noise: not a loop parameter
+    with pytest.raises(NotImplementedError):
+        train_native(model=fx, likelihood=lik, train_x=x, train_y=y, maxiter=2)
+    del lik._priors["noise_prior"]
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         train_native(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=2)
     with pytest.raises(ValueError):
