@@ -60,6 +60,7 @@ struct pgm_ws {
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
   int bh, bt;            // fused sweep: update-tile budgets of the head and row-solve launches (128x128 tiles)
+  int window;            // big single light curves: rows per window of the windowed fused sweep (0 = plain panels)
   // early inverse pass (fused sweep, one light curve): the late diagonal-block launches have fewer update tiles than
   // CUs; their spare workgroups form  R_ij = sum_p V_pi^T V_pj  over block rows p that are already final
   int early;             // 0 = off
@@ -72,7 +73,7 @@ struct pgm_ws {
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;
-  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; bool early; hipGraphExec_t exec; };
+  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
   // profiling
   bool prof_on;

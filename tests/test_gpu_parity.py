@@ -800,3 +800,36 @@ def test_early_inverse_pass_equals_the_plain_schedule(dev, monkeypatch, case):
     assert abs(float(outs["1"]["mll"]) - float(val)) < MLL_TOL
     for p in ("w", "mu", "v", "noise", "mean"):
         assert _rel(outs["1"][f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
+def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatch):
+    """41..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
+    the diagonal-block launches), the rows beyond it get one deep update per window.  Same factor, hence the same value bit
+    for bit, as the plain panel schedule (PGM_WINDOW=0) and as the early inverse pass switched off; gradients to rounding
+    of the different summation split; and the directional derivative along the gradient matches central differences."""
+    t, y, e = syn.cfg2(n_obs=5300)                              # 42 block rows
+    x, yy, nz = t.double(), y.double(), e.double() ** 2
+    h = syn.cfg_hypers(2, yy)
+    w, mu, v = h["w"], h["mu"].reshape(4, 1), h["v"].reshape(4, 1)
+    outs = {}
+    for name, env in (("windowed", {}), ("panels", {"PGM_WINDOW": "0"}), ("plain", {"PGM_WINDOW": "0", "PGM_EARLY": "0"})):
+        _hip.release_workspaces()
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        outs[name] = {k: t_.clone() for k, t_ in _hip_eval(dev, x, yy, h["mean"], nz, w, mu, v).items() if torch.is_tensor(t_)}
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    assert int(outs["windowed"]["info"]) == 0
+    assert float(outs["windowed"]["mll"]) == float(outs["panels"]["mll"]) == float(outs["plain"]["mll"])
+    for p in ("w", "mu", "v", "noise", "mean"):
+        for other in ("panels", "plain"):
+            assert _rel(outs["windowed"][f"g_{p}"].reshape(-1), outs[other][f"g_{p}"].reshape(-1)) < 1e-10, (p, other)
+    _hip.release_workspaces()
+    base = outs["windowed"]
+    g_ = {p: base[f"g_{p}"].cpu() for p in ("w", "mu", "v")}
+    gn = math.sqrt(sum(float((t_ ** 2).sum()) for t_ in g_.values()))
+    eps = 1e-6 / gn
+    plus = _hip_eval(dev, x, yy, h["mean"], nz, w + eps * g_["w"], mu + eps * g_["mu"], v + eps * g_["v"], need_grad=False)
+    minus = _hip_eval(dev, x, yy, h["mean"], nz, w - eps * g_["w"], mu - eps * g_["mu"], v - eps * g_["v"], need_grad=False)
+    fd = (float(plus["mll"]) - float(minus["mll"])) / (2 * eps)
+    assert abs(fd - gn * gn) < 1e-4 * gn * gn
