@@ -803,7 +803,7 @@ def test_early_inverse_pass_equals_the_plain_schedule(dev, monkeypatch, case):
 
 
 def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatch):
-    """41..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
+    """34..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
     the diagonal-block launches), the rows beyond it get one deep update per window.  Same factor, hence the same value bit
     for bit, as the plain panel schedule (PGM_WINDOW=0) and as the early inverse pass switched off; gradients to rounding
     of the different summation split; and the directional derivative along the gradient matches central differences."""
