@@ -156,6 +156,27 @@ def test_batched_equals_singles_and_oracle(dev):
         val, gr = orc.mll_value_grad_closed_form(xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
         assert abs(float(val) - float(out["mll"][i])) < MLL_TOL
         assert _rel(out["g_v"][i].reshape(-1), gr["v"].reshape(-1)) < GRAD_RTOL
+    # a handful of longer curves: the batch takes the fused sweep too (update tiles of all problems as fillers of the
+    # diagonal-block launches); a single curve of this length also starts its inverse pass inside the sweep, so its
+    # gradient sums are split differently: same factor (value bit for bit), gradients to rounding
+    B, n = 3, 1100
+    xs, ys, ns, ws, mus, vs, means = [], [], [], [], [], [], []
+    for i in range(B):
+        (t, y, e), per = syn.cfg3_lightcurve(10 + i, n_obs=n)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        xs.append(t.double().reshape(n, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+        ws.append(h["w"]); mus.append(h["mu"].reshape(4, 1)); vs.append(h["v"].reshape(4, 1)); means.append(h["mean"].expand(n))
+    out = evaluate_batch(st(xs), st(ys), st(means), st(ns), st(ws), st(mus), st(vs))
+    torch.cuda.synchronize()
+    for i in range(B):
+        single = _hip_eval(dev, xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
+        assert float(single["mll"]) == float(out["mll"][i])
+        for p in ("w", "mu", "v", "noise", "mean"):
+            assert _rel(single[f"g_{p}"].reshape(-1), out[f"g_{p}"][i].reshape(-1)) < 1e-11, p
+        val, gr = orc.mll_value_grad_closed_form(xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
+        assert abs(float(val) - float(out["mll"][i])) < MLL_TOL
+        for p in ("w", "mu", "v"):
+            assert _rel(out[f"g_{p}"][i].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
 def test_dense_kernel_entry_point(dev):
