@@ -121,7 +121,11 @@ class Workspace:
         _check(lib.pgm_workspace_create(byref(handle), idx, max_n, max_q, max_d, max_batch), "pgm_workspace_create")
         self.handle = handle
         self.max_n, self.max_q, self.max_d, self.max_batch = max_n, max_q, max_d, max_batch
-        self.bytes = int(lib.pgm_workspace_bytes(handle))
+
+    @property
+    def bytes(self) -> int:
+        """Device memory held now (the scratch of the early inverse pass and of prediction grows on first use)."""
+        return int(load().pgm_workspace_bytes(self.handle)) if getattr(self, "handle", None) else 0
 
     def close(self):
         if getattr(self, "handle", None):
