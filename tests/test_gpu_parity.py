@@ -854,3 +854,33 @@ def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatc
     minus = _hip_eval(dev, x, yy, h["mean"], nz, w - eps * g_["w"], mu - eps * g_["mu"], v - eps * g_["v"], need_grad=False)
     fd = (float(plus["mll"]) - float(minus["mll"])) / (2 * eps)
     assert abs(fd - gn * gn) < 1e-4 * gn * gn
+
+
+def test_one_workspace_many_problem_sizes(dev):
+    """A workspace serves problems of any size up to its maximum, each with its own captured launch sequence; the tables and
+    the scratch of the early inverse pass are shared between them.  Alternating sizes must not disturb earlier graphs."""
+    ws = _hip.Workspace(dev, 2304, 2, 1, 1)
+    w = torch.tensor([0.6, 0.3], dtype=D); mu = torch.tensor([[0.02], [0.11]], dtype=D); v = torch.tensor([[0.003], [0.01]], dtype=D)
+
+    def problem(n):
+        gen = torch.Generator().manual_seed(n)
+        x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 700)[0]
+        return x, torch.randn(n, generator=gen, dtype=D), 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+
+    def run(n):
+        x, y, nz = problem(n)
+        out = _hip.mll_value_grad(x.reshape(n, 1).to(dev), y.to(dev), torch.zeros(n, dtype=D, device=dev), nz.to(dev), None,
+                                  w.to(dev), mu.to(dev), v.to(dev), 0, 0.0, True, workspace=ws)
+        torch.cuda.synchronize()
+        return {k: t.clone() for k, t in out.items() if torch.is_tensor(t)}
+
+    first = {n: run(n) for n in (1100, 2300, 300, 1700)}
+    for n in (300, 2300, 1100, 1700, 1100):
+        again = run(n)
+        for k in ("mll", "g_w", "g_mu", "g_v", "g_noise", "g_mean"):
+            assert torch.equal(again[k], first[n][k]), (n, k)
+    x, y, nz = problem(1100)
+    val, gr = orc.mll_value_grad_closed_form(x, y, 0.0, nz, w, mu, v)
+    assert abs(float(first[1100]["mll"]) - float(val)) < MLL_TOL
+    assert _rel(first[1100]["g_mu"].reshape(-1), gr["mu"].reshape(-1)) < GRAD_RTOL
+    ws.close()
