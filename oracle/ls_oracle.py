@@ -72,6 +72,21 @@ def power(t, y, dy, freq, fit_mean=True, center_data=True):
     return out
 
 
+def multiband_fast(t, y, bands, dy, freq, fit_mean=True, center_data=True):
+    """Multiband periodogram, "fast" form (VanderPlas & Ivezic 2015; what ``pgmuvi/multiband_ls_significance.py:51-106`` asks
+    astropy for): per-band standard-normalised powers weighted by each band's reference chi^2 about its weighted mean."""
+    t = np.asarray(t, dtype=float); y = np.asarray(y, dtype=float); bands = np.asarray(bands)
+    chi2_0, powers = [], []
+    for b in np.unique(bands):
+        m = bands == b
+        dyb = None if dy is None else np.asarray(dy, dtype=float)[m]
+        w = np.ones(int(m.sum())) if dyb is None else dyb ** -2.0
+        chi2_0.append(np.sum(w * (y[m] - np.dot(w, y[m]) / w.sum()) ** 2))
+        powers.append(power(t[m], y[m], dyb, freq, fit_mean, center_data))
+    chi2_0 = np.asarray(chi2_0)
+    return np.dot(chi2_0 / chi2_0.sum(), np.asarray(powers))
+
+
 def power_by_least_squares(t, y, dy, f):
     """Independent definition: 1 - chi2(f) / chi2_ref with chi2(f) from an explicit weighted fit of
     (1, cos, sin) and chi2_ref from the weighted mean alone."""

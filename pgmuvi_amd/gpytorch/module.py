@@ -30,6 +30,10 @@ class Module(nn.Module):
     def forward(self, *inputs, **kwargs):
         raise NotImplementedError
 
+    def register_parameter(self, name, parameter=None, param=None):
+        """GPyTorch spells the keyword ``parameter`` (``pgmuvi/gps.py:1435-1462`` uses it); torch spells it ``param``."""
+        return super().register_parameter(name, parameter if parameter is not None else param)
+
     def __getattr__(self, name):
         try:
             return super().__getattr__(name)

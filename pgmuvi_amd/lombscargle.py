@@ -129,10 +129,51 @@ class LombScargle:
 
 
 class LombScargleMultiband:
-    """Importable placeholder (``pgmuvi/multiband_ls_significance.py:9`` imports the name at module level)."""
+    """``astropy.timeseries.LombScargleMultiband`` as pgmuvi uses it (``pgmuvi/multiband_ls_significance.py:51-106``, always with
+    ``method='fast'``): the multiband periodogram of VanderPlas & Ivezic (2015) in its "fast" form -- one floating-mean
+    Lomb-Scargle periodogram per band (the HIP kernel, one call per band), combined with weights
+    ``chi2_0[b] / sum(chi2_0)`` where ``chi2_0[b] = sum(((y - ybar_w) / dy)**2)`` over band b.  Restated from the published
+    method and gatspy's / astropy's description of it; astropy itself is not available here to compare against.  The
+    'flexible' method (a regularised multi-term model fit) is not implemented."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("the multiband periodogram is outside the scope of pgmuvi_amd (1-D Lomb-Scargle seeding only)")
+    def __init__(self, t, y, bands, dy=None, normalization="standard", nterms_base=1, nterms_band=1, reg_base=None,
+                 reg_band=1e-6, regularize_by_trace=True, center_data=True, fit_mean=True):
+        if normalization != "standard":
+            raise NotImplementedError("only normalization='standard' (astropy's default, what pgmuvi uses) is implemented")
+        self.t, self.y = _np(t).reshape(-1).astype(np.float64), _np(y).reshape(-1).astype(np.float64)
+        self.bands = np.asarray(_np(bands)).reshape(-1)
+        self.dy = None if dy is None else _np(dy).reshape(-1).astype(np.float64)
+        if not (self.t.shape == self.y.shape == self.bands.shape) or (self.dy is not None and self.dy.shape != self.t.shape):
+            raise ValueError("t, y, bands, dy must have the same shape")
+        self.normalization, self.center_data, self.fit_mean = normalization, center_data, fit_mean
+        self.nterms_base, self.nterms_band = nterms_base, nterms_band
+
+    def autofrequency(self, samples_per_peak=5, nyquist_factor=5, minimum_frequency=None, maximum_frequency=None,
+                      return_freq_limits=False):
+        return LombScargle(self.t, self.y).autofrequency(samples_per_peak, nyquist_factor, minimum_frequency, maximum_frequency,
+                                                         return_freq_limits)
+
+    def power(self, frequency, method="flexible", sb_method="auto", normalization="standard"):
+        if method != "fast":
+            raise NotImplementedError("LombScargleMultiband: only method='fast' (what pgmuvi uses) is implemented")
+        if normalization not in (None, "standard"):
+            raise NotImplementedError("only normalization='standard'")
+        f = np.asarray(_np(frequency), dtype=np.float64)
+        chi2_0, powers = [], []
+        for band in np.unique(self.bands):
+            m = self.bands == band
+            dyb = None if self.dy is None else self.dy[m]
+            w = np.ones(int(m.sum())) if dyb is None else dyb ** -2.0
+            yb = self.y[m]
+            chi2_0.append(float(np.sum(w * (yb - np.dot(w, yb) / w.sum()) ** 2)))
+            powers.append(LombScargle(self.t[m], yb, dyb, fit_mean=self.fit_mean, center_data=self.center_data).power(f.reshape(-1)))
+        chi2_0 = np.asarray(chi2_0)
+        return np.dot(chi2_0 / chi2_0.sum(), np.asarray(powers)).reshape(f.shape)
+
+    def autopower(self, method="flexible", sb_method="auto", normalization="standard", samples_per_peak=5, nyquist_factor=5,
+                  minimum_frequency=None, maximum_frequency=None):
+        f = self.autofrequency(samples_per_peak, nyquist_factor, minimum_frequency, maximum_frequency)
+        return f, self.power(f, method=method, sb_method=sb_method, normalization=normalization)
 
 
 def seed_frequencies(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], num_peaks=1, nyquist_factor=5,

@@ -884,3 +884,18 @@ def test_one_workspace_many_problem_sizes(dev):
     assert abs(float(first[1100]["mll"]) - float(val)) < MLL_TOL
     assert _rel(first[1100]["g_mu"].reshape(-1), gr["mu"].reshape(-1)) < GRAD_RTOL
     ws.close()
+
+
+def test_multiband_lomb_scargle_vs_oracle(dev):
+    """The multiband periodogram the reference's 2-D seeding asks for (``LombScargleMultiband(...).power(f, method='fast')``,
+    ``pgmuvi/multiband_ls_significance.py:51-106``): per-band powers by the HIP kernel, chi^2-weighted; config 4's 8 bands."""
+    from oracle import ls_oracle as lso
+    from pgmuvi_amd import lombscargle as L
+    X, Y, E = syn.cfg4(n_per_band=120)
+    t, bands, y, e = X[:, 0].double().numpy(), X[:, 1].numpy(), Y.double().numpy(), E.double().numpy()
+    for dy in (e, None):
+        mb = L.LombScargleMultiband(t, y, bands, dy=dy)
+        f = mb.autofrequency(nyquist_factor=3)
+        p = mb.power(f, method="fast")
+        assert np.allclose(p, lso.multiband_fast(t, y, bands, dy, f), rtol=1e-9, atol=1e-12)
+        assert 0.0 < p.max() <= 1.0

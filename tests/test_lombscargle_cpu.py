@@ -66,7 +66,7 @@ def test_class_surface_matches_oracle_and_astropy_conventions():
     with pytest.raises(NotImplementedError):
         L.LombScargle(t, y, e, nterms=2)
     with pytest.raises(NotImplementedError):
-        L.LombScargleMultiband(t, y, t)
+        L.LombScargleMultiband(t, y, np.zeros_like(t)).power(np.array([0.01]))       # astropy's default method is 'flexible'
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         L.LombScargle(t, y, e).power(np.array([0.01]))          # no GPU here, and no silent CPU path
 
@@ -82,3 +82,28 @@ def test_batched_seeding_finds_the_injected_periods():
     assert freqs.shape == (3, 2) and grid.ndim == 1
     for b in range(3):        # the leading period (amplitude 1) is the highest peak, to within one grid step
         assert abs(freqs[b, 0] - 1.0 / per[b]) < 1.5 * (grid[1] - grid[0]), (freqs[b], per[b])
+
+
+def test_multiband_fast_periodogram_vs_oracle():
+    """``LombScargleMultiband(...).power(f, method='fast')`` as ``pgmuvi/multiband_ls_significance.py`` uses it: per-band powers
+    (here through the oracle stand-in of the HIP kernel) combined with the chi^2 weights; a common period in every band
+    is the highest peak."""
+    rng = np.random.default_rng(3)
+    period = 37.0
+    ts, ys, bs, es = [], [], [], []
+    for b, (nb, amp) in enumerate(((60, 1.0), (45, 0.6), (80, 0.3))):
+        t = np.sort(rng.uniform(0, 400, nb))
+        e = 0.05 + 0.05 * rng.random(nb)
+        ts.append(t); bs.append(np.full(nb, b)); es.append(e)
+        ys.append(2.0 * b + amp * np.sin(2 * np.pi * t / period + 0.3 * b) + e * rng.standard_normal(nb))
+    t, y, bands, e = map(np.concatenate, (ts, ys, bs, es))
+    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(L, "_compute_device", lambda: torch.device("cpu")):
+        for dy in (e, None):
+            mb = L.LombScargleMultiband(t, y, bands, dy=dy)
+            f = mb.autofrequency(nyquist_factor=2)
+            assert np.array_equal(f, lso.autofrequency(t, nyquist_factor=2))
+            p = mb.power(f, method="fast")
+            assert p.shape == f.shape and np.allclose(p, lso.multiband_fast(t, y, bands, dy, f), rtol=0, atol=1e-13)
+            assert abs(1.0 / f[np.argmax(p)] - period) < 0.5
+            f2, p2 = mb.autopower(method="fast", nyquist_factor=2)
+            assert np.array_equal(f2, f) and np.array_equal(p2, p)
