@@ -860,6 +860,14 @@ __device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, 
   if (half == 0) P.dpart[b * P.sDpart + (int64_t)sp * P.np + jb * NB + c] = s + red[c];
 }
 
+// The same items as a launch of their own: big batches of small problems have tens of thousands of them, and inside the
+// inverse/gradient launch they would run at its occupancy (two workgroups per CU, 64 KB of LDS each).
+__global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
+  __shared__ double red[NB];
+  if (P.info[blockIdx.z] != 0) return;
+  ainv_diag_item(P, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
 template <int D, int ORDER>
 __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   using C = CfgBig;
