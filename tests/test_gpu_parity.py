@@ -899,3 +899,36 @@ def test_multiband_lomb_scargle_vs_oracle(dev):
         p = mb.power(f, method="fast")
         assert np.allclose(p, lso.multiband_fast(t, y, bands, dy, f), rtol=1e-9, atol=1e-12)
         assert 0.0 < p.max() <= 1.0
+
+
+def test_performance_guards(dev):
+    """Coarse timing guards (2-3x above what one MI355X measures) for the shapes a change to one schedule can break without
+    any parity test noticing: one N=4096 light curve, a shard of 2048-point curves, thousands of short curves per call."""
+    import time
+
+    def timed(B, n, reps):
+        xs, ys, ns, ws_, mus, vs, ms = [], [], [], [], [], [], []
+        for i in range(min(B, 8)):
+            (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=n)
+            h = syn.cfg_hypers(3, y.double(), lead_period=per)
+            xs.append(t.double().reshape(-1, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+            ws_.append(h["w"]); mus.append(h["mu"].reshape(4, 1)); vs.append(h["v"].reshape(4, 1)); ms.append(h["mean"].expand(n))
+        rep = (B + len(xs) - 1) // len(xs)
+        st = lambda L: torch.stack(L).repeat(rep, *([1] * L[0].dim()))[:B].to(dev).contiguous()
+        x, y, nz, w, mu, v, m = st(xs), st(ys), st(ns), st(ws_), st(mus), st(vs), st(ms)
+        if B == 1:
+            x, y, nz, w, mu, v, m = x[0], y[0], nz[0], w[0], mu[0], v[0], m[0]
+        f = lambda: _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True)
+        out = f(); torch.cuda.synchronize()
+        assert int(out["info"].abs().max()) == 0
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        _hip.release_workspaces()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    limits = {(1, 4096): 5.0, (1, 1024): 1.2, (16, 2048): 10.0, (1024, 256): 5.0, (2048, 89): 2.5, (1, 8192): 25.0}
+    for (B, n), lim in limits.items():
+        ms = timed(B, n, 5)
+        assert ms < lim, f"{B} x N={n}: {ms:.2f} ms per call (guard {lim} ms)"
