@@ -902,7 +902,7 @@ def test_multiband_lomb_scargle_vs_oracle(dev):
 
 
 def test_performance_guards(dev):
-    """Coarse timing guards (2-3x above what one MI355X measures) for the shapes a change to one schedule can break without
+    """Coarse timing guards (about 4x above what one MI355X measures, best of three) for the shapes a change to one schedule can break without
     any parity test noticing: one N=4096 light curve, a shard of 2048-point curves, thousands of short curves per call."""
     import time
 
@@ -921,14 +921,18 @@ def test_performance_guards(dev):
         f = lambda: _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True)
         out = f(); torch.cuda.synchronize()
         assert int(out["info"].abs().max()) == 0
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            f()
-        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(3):                                       # best of three blocks: a busy host must not fail this
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / reps * 1e3)
         _hip.release_workspaces()
-        return (time.perf_counter() - t0) / reps * 1e3
+        return best
 
-    limits = {(1, 4096): 5.0, (1, 1024): 1.2, (16, 2048): 10.0, (1024, 256): 5.0, (2048, 89): 2.5, (1, 8192): 25.0}
+    # (measured: 2.23, 0.43, 4.2, 1.8, 0.91, 11.5 ms; the schedule bug this guards against cost 6.5x)
+    limits = {(1, 4096): 9.0, (1, 1024): 2.5, (16, 2048): 16.0, (1024, 256): 8.0, (2048, 89): 4.0, (1, 8192): 45.0}
     for (B, n), lim in limits.items():
         ms = timed(B, n, 5)
         assert ms < lim, f"{B} x N={n}: {ms:.2f} ms per call (guard {lim} ms)"
