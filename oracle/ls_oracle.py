@@ -17,10 +17,22 @@ and the false-alarm formulas of Baluev (2008) as astropy documents them.  astrop
 ``method='auto'`` evaluates the same periodogram with an FFT-based approximation (Press & Rybicki) whose
 result differs from the exact sums by ~1e-3 relative; the exact sums are the reference point here.
 
-**Parity pinned only by one recorded reference output**: with this oracle behind the astropy-shaped shim,
-the reference's own ``fit()`` reproduces the initial frequencies the comparison notebook printed
-(``tests/test_dropin_reference.py``); the FAP formulas are restated from memory of astropy's
-``_statistics.py`` and labelled unverified.  Independent known-answer check available here: the
+``power_fast`` restates that approximation (extirpolation onto a regular grid + one inverse FFT per trigonometric
+sum) because the reference's recorded outputs come from it: on pgmuvi's grids (> 200 regular frequencies) astropy's
+``method='auto'`` resolves to it, and it differs from the exact sums by up to 1e-2 in the power at the high-frequency
+end -- enough to swap the order of two near-equal peaks.
+
+**Pinned by the recorded outputs the reference holds** (``tests/test_dropin_reference.py``, all through the
+reference's own ``fit_LS`` on the astropy-shaped shim): the comparison notebook's initial frequencies (0.0067,
+0.0154); the Lomb-Scargle notebook's five 1-D peaks to the 6 printed digits with their significance flags
+(``docs/source/notebooks/PGMUVI_Lomb_Scargle.ipynb`` cells 10/12/34: exact sums give the same five peaks with the
+4th and 5th swapped -- their powers are 0.3913 and 0.3910 --, ``power_fast`` gives the recorded order, i.e. the
+'davies' / 'single' false-alarm formulas and the Benjamini-Hochberg step decide as recorded); the
+``use_best_band_init=True`` periodogram's peak period / height / prominence (149.170715 / 0.992789 / 0.859738, cell 20).
+**Not reproduced**: the *default multiband* numbers of that cell (height 0.909449, prominence 0.579050): the
+chi^2-weighted "fast" multiband form restated in ``multiband_fast`` gives 0.984977 / 0.824881, and so do a restated
+'flexible' form and every weighting tried (tools notes in DESIGN.md section 5) -- the multiband combination stays
+unverified.  Independent known-answer check available here: the
 periodogram is 1 - chi^2(f)/chi^2_ref of an explicit weighted least-squares fit (``numpy.linalg.lstsq``).
 
 Only ``tests/`` may import this module.
@@ -70,6 +82,80 @@ def power(t, y, dy, freq, fit_mean=True, center_data=True):
         d = cc * ss - cs * cs
         out[lo:lo + 2048] = (ss * yc * yc + cc * ys * ys - 2.0 * cs * yc * ys) / (yy * d)
     return out
+
+
+def _spread(x, h, n, m=4):
+    """Extirpolation (Press & Rybicki 1989): each sample h_k at the fractional position x_k is spread onto the ``m``
+    nearest grid points with Lagrange weights, so that sum_j grid_j g(j) == sum_k h_k g(x_k) for polynomials g of
+    degree < m."""
+    grid = np.zeros(n, dtype=h.dtype)
+    on = x % 1 == 0
+    np.add.at(grid, x[on].astype(int), h[on])
+    x, h = x[~on], h[~on]
+    lo = np.clip((x - m // 2).astype(int), 0, n - m)
+    for j in range(m):
+        wgt = np.ones_like(x)
+        for i in range(m):
+            if i != j:
+                wgt = wgt * (x - lo - i) / (j - i)
+        np.add.at(grid, lo + j, h * wgt)
+    return grid
+
+
+def _trig_sums_fft(t, h, f0, df, nf, factor=1, oversampling=5, m=4):
+    """S_k = sum_i h_i sin(2 pi f_k t_i), C_k likewise, f_k = factor (f0 + k df), by extirpolation of h onto a grid of
+    ``2**ceil(log2(oversampling nf))`` points and one inverse FFT (astropy's defaults: oversampling 5, 4-point spread)."""
+    f0, df = f0 * factor, df * factor
+    nfft = 1 << int(nf * oversampling - 1).bit_length()
+    t0 = t.min()
+    h = h.astype(complex)
+    if f0 > 0:
+        h = h * np.exp(2j * np.pi * f0 * (t - t0))
+    grid = _spread(((t - t0) * nfft * df) % nfft, h, nfft, m)
+    z = np.fft.ifft(grid)[:nf] * nfft
+    if t0 != 0:
+        z = z * np.exp(2j * np.pi * t0 * (f0 + df * np.arange(nf)))
+    return z.imag, z.real
+
+
+def power_fast(t, y, dy, f0, df, nf, fit_mean=True, center_data=True):
+    """The FFT approximation astropy's ``method='auto'`` takes on a regular grid of more than 200 frequencies
+    (``LombScargle.power(freq, assume_regular_frequency=True)``, ``/root/reference/pgmuvi/lightcurve.py:4514``): the same
+    floating-mean periodogram in its tau form, with the three pairs of trigonometric sums taken from extirpolated FFTs."""
+    t = np.asarray(t, dtype=float); y = np.asarray(y, dtype=float)
+    w = np.ones_like(t) if dy is None else np.asarray(dy, dtype=float) ** -2.0
+    w = w / w.sum()
+    if center_data or fit_mean:
+        y = y - np.dot(w, y)
+    sh, ch = _trig_sums_fft(t, w * y, f0, df, nf)
+    s2, c2 = _trig_sums_fft(t, w, f0, df, nf, factor=2)
+    if fit_mean:
+        s, c = _trig_sums_fft(t, w, f0, df, nf)
+        tan2 = (s2 - 2.0 * s * c) / (c2 - (c * c - s * s))
+    else:
+        tan2 = s2 / c2
+    c2w = 1.0 / np.sqrt(1.0 + tan2 * tan2)
+    s2w = tan2 * c2w
+    cw = np.sqrt(0.5) * np.sqrt(1.0 + c2w)
+    sw = np.sqrt(0.5) * np.sign(s2w) * np.sqrt(1.0 - c2w)
+    yc, ys = ch * cw + sh * sw, sh * cw - ch * sw
+    cc = 0.5 * (1.0 + c2 * c2w + s2 * s2w)
+    ss = 0.5 * (1.0 - c2 * c2w - s2 * s2w)
+    if fit_mean:
+        cc = cc - (c * cw + s * sw) ** 2
+        ss = ss - (s * cw - c * sw) ** 2
+    return (yc * yc / cc + ys * ys / ss) / np.dot(w, y * y)
+
+
+def power_auto(t, y, dy, freq, fit_mean=True, center_data=True):
+    """astropy's ``method='auto'`` rule for the single-term periodogram: the FFT approximation when the grid is regular
+    and longer than 200 frequencies, the exact sums otherwise."""
+    freq = np.asarray(freq, dtype=float)
+    if freq.ndim == 1 and freq.size > 200:
+        d = np.diff(freq)
+        if np.allclose(d, d[0]) and d[0] > 0:
+            return power_fast(t, y, dy, freq[0], d[0], freq.size, fit_mean, center_data)
+    return power(t, y, dy, freq, fit_mean, center_data)
 
 
 def multiband_fast(t, y, bands, dy, freq, fit_mean=True, center_data=True):

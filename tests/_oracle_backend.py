@@ -90,6 +90,17 @@ def lomb_scargle(t, y, dy, freq, fit_mean=True, center_data=True):
     return torch.as_tensor(out, dtype=torch.float64, device=y.device)
 
 
+def lomb_scargle_auto(t, y, dy, freq, fit_mean=True, center_data=True):
+    """TEST-ONLY stand-in with astropy's ``method='auto'`` rule (FFT approximation on long regular grids)."""
+    import numpy as np
+    from oracle import ls_oracle
+    f = freq.detach().cpu().numpy()
+    out = np.stack([ls_oracle.power_auto(t[b].detach().cpu().numpy(), y[b].detach().cpu().numpy(),
+                                         None if dy is None else dy[b].detach().cpu().numpy(), f, fit_mean, center_data)
+                    for b in range(y.shape[0])])
+    return torch.as_tensor(out, dtype=torch.float64, device=y.device)
+
+
 def mll_dense(A, r, jitter=0.0, need_grad=True, workspace=None):
     """TEST-ONLY stand-in for ``pgmuvi_amd._hip.mll_dense``: value by a torch Cholesky, gradients by autograd."""
     batched = A.dim() == 3

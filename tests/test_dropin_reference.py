@@ -134,6 +134,50 @@ def test_reference_fit_reproduces_the_notebooks_recorded_result():
     assert "NOTEBOOK_PIN_OK" in out
 
 
+def test_reference_2d_fit_reproduces_the_notebooks_recorded_result_and_pins_the_kernel_form():
+    """The comparison notebook's "pgmuvi 2D" cell (notebook lines 1463-1552; model ``pgmuvi/gps.py:302-318``, constraints
+    ``pgmuvi/lightcurve.py:3883-3906``) starts from a deterministic state (no Lomb-Scargle seeding, no random draw) and its
+    recorded output holds the stop iteration (348), the stop statistic (9.444e-06), the loss (0.904) and the fitted time
+    frequencies (13.842627, twice).  The reference's own ``Lightcurve.fit`` on shim + oracle lands on all of them with
+    GPyTorch's prod_d sum_q kernel (dim_order 0) -- frequencies to every printed digit -- and on none of them with
+    sum_q prod_d (dim_order 1)."""
+    out = _run("""
+        sys.path.insert(0, %r)
+        import make_notebook_pin as nb
+        rec = nb.NOTEBOOK_2D
+        got = {}
+        for order in (0, 1):
+            torch.manual_seed(0)
+            lc = nb.build_lightcurve_2d()
+            assert len(lc.xdata) == rec["nb_n_points"]
+            assert sorted(np.unique(lc.xdata[:, 1].numpy(), return_counts=True)[1].tolist()) == sorted(rec["nb_band_counts"])
+            res = nb.run_fit_2d(lc, ob.mll_value_grad, order)
+            loss = [float(v) for v in res["loss"]]
+            f = lc.model.covar_module.mixture_means.detach().numpy()[:, 0, 0]
+            got[order] = (len(loss) - 1, loss[-1], f, float(np.std(loss[-30:])))
+            if order == 0:
+                # the initial state the notebook printed
+                assert abs(float(np.ravel(res["mean_module.constant"][0])[0]) - rec["nb_init_constant"]) < 1e-7
+                assert np.allclose(np.ravel(res["covar_module.mixture_means"][0]), rec["nb_init_means"], atol=5e-5)
+                assert np.allclose(np.ravel(res["covar_module.mixture_weights"][0]), rec["nb_init_weights"], atol=5e-5)
+                assert np.allclose(np.ravel(res["covar_module.mixture_scales"][0]), rec["nb_init_scales"], atol=5e-5)
+        stop, loss, f, sv = got[0]
+        assert stop == rec["nb_progress_bar_stop"], stop                       # tqdm shows the loop index at the break
+        assert round(loss, 3) == rec["nb_final_loss"], loss
+        assert np.all(np.abs(f - np.asarray(rec["nb_final_time_freqs"])) < 2e-6), f   # float32 print precision
+        assert abs(sv / rec["nb_stopval"] - 1) < 0.01, sv
+        stop1, loss1, f1, _ = got[1]
+        assert abs(stop1 - rec["nb_progress_bar_stop"]) > 100, stop1
+        assert abs(loss1 - rec["nb_final_loss"]) > 0.02, loss1
+        assert np.all(np.abs(f1 - np.asarray(rec["nb_final_time_freqs"])) > 0.3), f1
+        # the committed fixture the GPU twin reads is this run
+        pin = np.load(%r)
+        assert int(pin["order0_n_losses"]) == stop + 1 and abs(float(pin["order0_loss"][-1]) - loss) < 1e-12
+        print("NOTEBOOK_2D_PIN_OK", got)
+    """ % (os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests", "golden", "notebook_pin_2d.npz")))
+    assert "NOTEBOOK_2D_PIN_OK" in out
+
+
 def test_reference_default_fit_seeds_from_lomb_scargle_like_the_notebook():
     """``fit()`` without ``periods``/``guess``: the reference's own ``fit_LS`` (lightcurve.py:4214-4611) runs on the
     astropy-shaped shim (periodogram by the oracle stand-in here, by the HIP kernel on the GPU) and seeds the mixture
@@ -155,6 +199,57 @@ def test_reference_default_fit_seeds_from_lomb_scargle_like_the_notebook():
         print("LS_SEED_OK", f[:2])
     """ % os.path.join(ROOT, "tests", "golden"))
     assert "LS_SEED_OK" in out
+
+
+def test_reference_fit_LS_reproduces_the_lomb_scargle_notebooks_recorded_peaks():
+    """``docs/source/notebooks/PGMUVI_Lomb_Scargle.ipynb`` (cells 10/12/34 and 20) recorded, for a seeded light curve,
+    five peak frequencies to 6 digits with their significance flags, the grid length, and the peak period / height /
+    prominence of the ``use_best_band_init=True`` periodogram.  The reference's own ``fit_LS``
+    (``pgmuvi/lightcurve.py:4214-4611``) on the astropy-shaped shim reproduces them: with the exact sums (what the HIP kernel
+    evaluates) as a set -- the 4th and 5th peaks, whose powers differ by 4e-4, come out swapped --, and in the recorded
+    order with the restated FFT approximation astropy's ``method='auto'`` takes on such a grid.  The default multiband
+    periodogram's recorded height (0.909449) is NOT reproduced by the chi^2-weighted per-band form (0.984977); asserted
+    here so that the discrepancy stays visible."""
+    out = _run("""
+        sys.path.insert(0, %r)
+        from pgmuvi_amd import lombscargle
+        assert lombscargle.install_as_astropy(force=True)
+        import make_ls_notebook_pin as nb
+        from scipy.signal import find_peaks, peak_prominences
+        rec = nb.RECORDED
+        lc2d = nb.build_one_period()
+        lc1d = lc2d.select_bands(["band 0"])
+        assert len(lc1d.xdata) == rec["nb1d_n_points"]
+        got = {}
+        for name, ls in (("exact", ob.lomb_scargle), ("auto", ob.lomb_scargle_auto)):
+            with mock.patch.object(_hip, "lomb_scargle", ls), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+                f, sig, grid, power = lc1d.fit_LS(freq_only=False, num_peaks=5, return_full=True)
+                fb, pb = lc2d.fit_LS(freq_only=True, use_best_band_init=True)
+                fd, pd_ = lc2d.fit_LS(freq_only=True)
+            assert len(grid) == rec["nb1d_grid_length"]
+            got[name] = ([round(float(v), 6) for v in f], [bool(v) for v in sig])
+            fb, pb = fb.numpy(), pb.numpy()
+            pk, _ = find_peaks(pb)
+            k = pk[np.argmax(pb[pk])]
+            best = (1.0 / fb[k], pb[k], peak_prominences(pb, pk)[0][np.argmax(pb[pk])])
+            assert abs(best[0] - rec["nbmb_best_band"][0]) < 1e-5 and abs(best[1] - rec["nbmb_best_band"][1]) < 2e-6 \
+                and abs(best[2] - rec["nbmb_best_band"][2]) < 2e-6, best
+            got[name + "_default_height"] = float(pd_.max())
+        assert got["auto"] == (rec["nb1d_peak_freqs"], rec["nb1d_peak_significant"]), got["auto"]
+        assert sorted(got["exact"][0]) == sorted(rec["nb1d_peak_freqs"]) and got["exact"][0][:3] == rec["nb1d_peak_freqs"][:3]
+        assert got["exact"][1] == rec["nb1d_peak_significant"]
+        # the multiband combination: recorded 0.909449, the chi^2-weighted form gives 0.984977 -- NOT reproduced
+        assert abs(got["exact_default_height"] - 0.984977) < 2e-6 and abs(got["exact_default_height"] - rec["nbmb_default"][1]) > 0.07
+        # two-period light curve + dense band (cell 34): band counts, the strongest peak and the 66-day peak are the recorded ones
+        lc4 = nb.build_two_periods_with_dense_band()
+        assert [int(np.sum(lc4.band == b)) for b in np.unique(lc4.band)] == rec["nbmb2_band_counts"]
+        with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle_auto), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+            f8, s8 = lc4.fit_LS(freq_only=False, num_peaks=8, return_full=False)
+        f8 = [round(float(v), 6) for v in f8]
+        assert f8[0] == rec["nbmb2_peak_freqs"][0] and bool(s8[0]) and rec["nbmb2_peak_freqs"][7] in f8, f8
+        print("LS_NOTEBOOK_PIN_OK", got)
+    """ % os.path.join(ROOT, "tests", "golden"))
+    assert "LS_NOTEBOOK_PIN_OK" in out
 
 
 def test_native_trainer_hook_routes_fit_and_falls_back():

@@ -454,6 +454,63 @@ def test_notebook_fit_on_the_gpu_lands_on_the_recorded_result(dev, golden_dir):
     assert np.all(np.abs(f / np.sort(p["nb_final_freqs"]) - 1) < 2e-3), f
 
 
+def _notebook_2d_model(dev, p):
+    """The state ``Lightcurve.fit(model='2D', num_mixtures=2)`` trains from in the notebook's 2-D cell: float32 parameters at
+    raw = 0 on float64 data, ``set_default_constraints``' Interval constraints (bounds from the fixture)."""
+    x, y, noise = (torch.as_tensor(p[k], dtype=D).to(dev) for k in ("x", "y", "noise"))
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise)
+    assert str(p["param_dtype"]) == "torch.float32"
+    model = _make_model(dev, x, y, lik, 2, d=2, dtype=torch.float32)
+    model.mean_module.register_constraint("raw_constant", g.constraints.Interval(float(p["constant_bounds"][0]), float(p["constant_bounds"][1])))
+    model.covar_module.register_constraint("raw_mixture_means", g.constraints.Interval(float(p["means_bounds"][0]), float(p["means_bounds"][1])))
+    return model, lik, x, y, noise
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_notebook_2d_recorded_output(dev, golden_dir, order):
+    """HIP path at the end points of the reference-driven re-runs of the comparison notebook's "pgmuvi 2D" cell
+    (tests/golden/make_notebook_pin.py, one per kernel form): equal to the oracle to round-off; with GPyTorch's
+    prod_d sum_q form (dim_order 0) the loss is the one the notebook recorded (0.904), with sum_q prod_d it is not."""
+    p = _load(golden_dir, "notebook_pin_2d.npz")
+    x, y, noise = (torch.as_tensor(p[k], dtype=D) for k in ("x", "y", "noise"))
+    w, mu, v = (torch.as_tensor(p[f"order{order}_final_{k}"], dtype=D) for k in ("w", "mu", "v"))
+    c = float(p[f"order{order}_final_c"])
+    out = _hip_eval(dev, x, y, c, noise, w, mu, v, order=order)
+    val, gr = orc.mll_value_grad_closed_form(x, y, torch.full_like(y, c), noise, w, mu, v, order, 0.0)
+    assert int(out["info"]) == 0
+    assert abs(float(out["mll"]) - float(val)) < MLL_TOL
+    for k in ("w", "mu", "v"):
+        assert _rel(out[f"g_{k}"].reshape(-1), gr[k].reshape(-1)) < GRAD_RTOL
+    # the stored loss is the one AFTER which the last optimiser step was taken: one step of a converged fit apart
+    assert abs(-float(out["mll"]) - float(p[f"order{order}_loss"][-1])) < 1e-4
+    if order == 0:
+        assert round(-float(out["mll"]), 3) == float(p["nb_final_loss"])
+    else:
+        assert abs(-float(out["mll"]) - float(p["nb_final_loss"])) > 0.02
+
+
+def test_notebook_2d_fit_on_the_gpu_lands_on_the_recorded_result(dev, golden_dir):
+    """The whole 2-D fit of that notebook cell on the HIP path (our mirror of trainers.train; fit()'s defaults AdamW, stop 1e-5
+    over 30 losses, plus the cell's lr 0.05 / miniter 50 / 1000 iterations): the start is deterministic, and the run must end where
+    the reference's recorded output says it ended -- loop index 348 at the early stop, loss 0.904, time frequencies 13.842627 -- and
+    follow the oracle-driven trajectory of the reference's own ``Lightcurve.fit`` stored in the fixture."""
+    from pgmuvi_amd.trainers import train
+    p = _load(golden_dir, "notebook_pin_2d.npz")
+    model, lik, x, y, _ = _notebook_2d_model(dev, p)
+    init = model.covar_module.mixture_means.detach().cpu().numpy().reshape(-1)
+    assert np.allclose(init, p["nb_init_means"], atol=5e-5)                 # 9.4067 = midpoint of the Interval at raw 0
+    assert abs(float(model.mean_module.constant) - float(p["nb_init_constant"])) < 1e-7
+    res = train(model=model, likelihood=lik, train_x=x, train_y=y, maxiter=1000, miniter=50, stop=1e-5, stopavg=30, lr=0.05,
+                optim="AdamW", progress=False)
+    loss = np.asarray([float(v) for v in res["loss"]])
+    f = model.covar_module.mixture_means.detach().cpu().numpy()[:, 0, 0]
+    assert len(loss) - 1 == int(p["nb_progress_bar_stop"]), len(loss)
+    assert round(float(loss[-1]), 3) == float(p["nb_final_loss"]), loss[-1]
+    assert np.all(np.abs(f - p["nb_final_time_freqs"]) < 5e-6), f
+    ref = p["order0_loss"]
+    assert len(ref) == len(loss) and np.max(np.abs(ref - loss)) < 1e-5      # float32 parameters: trajectories agree to their rounding
+
+
 def test_device_resident_training_loop_equals_the_host_loop(dev):
     """``train_device`` (one captured iteration replayed, losses and
     parameters logged on the device) follows the same trajectory as the reference-shaped ``train``."""
@@ -571,6 +628,46 @@ def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
         assert np.allclose(PB[i].cpu().numpy(), lso.power(ts[i].numpy(), ys[i].numpy(), es[i].numpy(), g2.cpu().numpy()), rtol=1e-9, atol=1e-12)
     freqs, pows, grid3 = L.seed_frequencies(T, Y, E, num_peaks=3)
     assert freqs.shape == (4, 3) and np.isfinite(freqs).all()
+
+
+def test_lomb_scargle_notebook_recorded_peaks(dev, golden_dir):
+    """The HIP periodogram on the light curves of the reference's Lomb-Scargle notebook (tests/golden/make_ls_notebook_pin.py):
+    equal to the oracle's exact sums, and the five strongest peaks of band 0 are the five frequencies the notebook recorded
+    (``fit_LS``'s peak rule: ``find_peaks(power, distance=5)`` by decreasing power), the first three in the recorded order
+    (the recorded order of the 4th and 5th, whose exact powers differ by 4e-4, is that of astropy's FFT approximation --
+    ``oracle/ls_oracle.power_fast``); 'davies' on the maximum and 'single' + Benjamini-Hochberg on the rest flag only the
+    first as significant, as recorded; the best-band periodogram of the three-band curve peaks at the recorded period/height."""
+    from scipy.signal import find_peaks
+    from pgmuvi_amd import lombscargle as L
+    from oracle import ls_oracle as lso
+    p = _load(golden_dir, "ls_notebook_pin.npz")
+    t, wl, y, dy = (p["one_" + k] for k in ("t", "wavelength", "y", "dy"))
+    m = wl == np.unique(wl)[0]
+    assert int(m.sum()) == int(p["nb1d_n_points"])
+    ls = L.LombScargle(t[m], y[m], dy[m])
+    f = ls.autofrequency(nyquist_factor=5)
+    assert len(f) == int(p["nb1d_grid_length"])
+    pw = ls.power(f, assume_regular_frequency=True)
+    assert np.allclose(pw, lso.power(t[m], y[m], dy[m], f), rtol=1e-9, atol=1e-12)
+    pk_all, _ = find_peaks(pw, distance=5)
+    pk_all = pk_all[np.argsort(pw[pk_all])][::-1]
+    pk = pk_all[:5]
+    got = [round(float(v), 6) for v in f[pk]]
+    rec = [round(float(v), 6) for v in p["nb1d_peak_freqs"]]
+    assert sorted(got) == sorted(rec) and got[:3] == rec[:3], got
+    assert abs(1.0 / f[pk[0]] - float(p["nbmb_best_band"][0])) < 1e-5 and abs(pw[pk[0]] - float(p["nbmb_best_band"][1])) < 2e-6
+    assert float(ls.false_alarm_probability(pw.max(), method="davies")) < 0.05
+    fap = ls.false_alarm_probability(pw[pk_all], method="single")
+    order = np.argsort(fap)
+    npk = len(pk_all)
+    passed = fap[order] <= np.arange(1, npk + 1) / npk * 0.05               # Benjamini-Hochberg over all peaks, as fit_LS applies it
+    nsig = (np.where(passed)[0].max() + 1) if passed.any() else 0
+    flags = np.zeros(npk, dtype=bool); flags[order[:nsig]] = True; flags[0] = True
+    assert flags[:5].tolist() == [bool(v) for v in p["nb1d_peak_significant"]]
+    # the multiband periodogram (per-band HIP periodograms, chi^2-weighted) equals the oracle's restatement of it
+    mb = L.LombScargleMultiband(t, y, wl, dy)
+    fm = mb.autofrequency(nyquist_factor=5)
+    assert np.allclose(mb.power(fm, method="fast"), lso.multiband_fast(t, y, wl, dy, fm), rtol=1e-9, atol=1e-12)
 
 
 def test_dense_backend_vs_oracle(dev):
