@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- marginal-log-likelihood evaluations/sec of the MI355X hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--batch B]                      # headline: weak scaling
+    python bench.py --gpus N --steps K --warmup W --total-batch B [--n 2048]       # strong scaling of one B-light-curve batch
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A *step* is one pass of the hot path -- SM kernel build + blocked Cholesky MLL + full
@@ -11,8 +12,17 @@ fp64; default B=1 = BASELINE.json configs[1], "Single 1D Lightcurve").  Inputs a
 resident in HBM before the timed region.  With N>1 GPUs every rank evaluates its own
 light curves (weak scaling, no data-path collective) and one RCCL all_gather of the
 log-likelihoods closes each step.  Rank 0 prints ONE JSON line.
+
+``--total-batch B`` switches to STRONG scaling (north_star: "a 4096-lightcurve batch"; BASELINE configs[2]: 512 x N=2048):
+a step is one evaluation of the WHOLE batch of B config-3 light curves -- block-partitioned over the ranks
+(``pgmuvi_amd.batch.shard_bounds``), each shard in memory-bounded chunks through the batched entry point, ONE all_gather of
+the B log-likelihoods -- and ``value`` = B * steps / elapsed.  The default invocation also appends a short strong-scaling
+measurement (``strong_scaling``: configs[2] and a 4096 x N=4096 batch) to the weak-scaling line, so that the driver's own
+N=1,2,4,8 runs record both.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -25,9 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pgmuvi_amd import _hip, synthetic as syn  # noqa: E402
-from pgmuvi_amd.batch import gather_logliks  # noqa: E402
+from pgmuvi_amd.batch import default_chunk, gather_logliks, make_shard, sharded_batch_step, shard_bounds  # noqa: E402
 
-PMC_FILE = "r01_pmc_hbm_traffic_v3.json"
+PMC_GLOB = "r*_pmc_hbm_traffic*.json"   # tools/pmc_traffic.py output; only a file measured on the CURRENT library is quoted
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet "FP64 matrix" (the guides list no fp64 MFMA figure)
 NB = 128
 
@@ -60,20 +70,40 @@ def trsm_flops(n, need_grad=True):
     return blocks * 2.0 * NB ** 3
 
 
-def cpu_baseline(n, reps):
-    """The oracle (torch-CPU restatement of the reference path, NOT GPyTorch) timed on the
-    host cores: value + gradient by autograd through the dense graph, as loss.backward()
-    does in the reference."""
-    from oracle import sm_mll_oracle as orc
+def _host_threads():
     # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(avail, 16)))
-    t, y, e = syn.cfg2(n_obs=n)
+    return max(1, min(avail, 16))
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n, reps, recipe="cfg2"):
+    """The oracle (torch-CPU restatement of the reference path, NOT GPyTorch) timed on the
+    host cores: value + gradient by autograd through the dense graph, as loss.backward()
+    does in the reference.  Median of ``reps`` (>= 5) after one warm-up."""
+    from oracle import sm_mll_oracle as orc
+    torch.set_num_threads(_host_threads())
+    if recipe == "cfg2":
+        t, y, e = syn.cfg2(n_obs=n)
+        h = syn.cfg_hypers(2, y.double())
+        what = f"the same N={n} Q=4 light curve"
+    else:
+        (t, y, e), per = syn.cfg3_lightcurve(0, n_obs=n)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        what = f"light curve 0 of the batch (N={n}, Q=4)"
     x64, y64, nz = t.double(), y.double(), e.double() ** 2
-    h = syn.cfg_hypers(2, y64)
     mu, v = h["mu"].reshape(-1, 1), h["v"].reshape(-1, 1)
     orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)      # warm-up
     times = []
@@ -84,8 +114,139 @@ def cpu_baseline(n, reps):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return dict(value=1.0 / med, unit="evals/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{reps} value+grad evaluations (1 warm-up) of the same N={n} Q=4 light curve, median {med * 1e3:.0f} ms"), float(val)
+    return dict(value=1.0 / med, unit="evals/s", cores=torch.get_num_threads(), kind="port", cpu_model=_cpu_model(),
+                sample=f"{reps} value+grad evaluations (1 warm-up) of {what}, median {med * 1e3:.0f} ms; torch-CPU restatement of the "
+                       "reference path (oracle/), not GPyTorch"), float(val)
+
+
+def lib_sha16():
+    return hashlib.sha256(open(_hip.lib_path(), "rb").read()).hexdigest()[:16]
+
+
+def measured_traffic(fused):
+    """Memory-side bytes per sweep launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate
+    runs, FETCH x2 for gfx950; tools/pmc_traffic.py) -- quoted only when that file was measured on the library that is
+    running now (the file records the library's sha256); a stale file gives ``None``."""
+    sha = lib_sha16()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB)), reverse=True):
+        pmc = json.load(open(path))
+        if pmc.get("_lib_sha16") != sha:
+            continue
+        rows = [v for k, v in pmc.items() if isinstance(v, dict) and
+                (k.startswith("k_update") or (fused and (k.startswith("k_diag") or k.startswith("k_trsm"))))]
+        tot = sum(r["launches"] for r in rows)
+        if tot:
+            return (sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot,
+                    f"profiles/{os.path.basename(path)} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, same workload, "
+                    f"same library sha256 {sha})")
+    return None, f"no profiles/{PMC_GLOB} measured on this library (sha256 {sha}): see tools/pmc_traffic.py"
+
+
+def sweep_roofline(prof, ws, n, nloc, steps):
+    """``roofline`` object of the factorisation sweep's tile GEMM from the per-launch HIP-event times of ``steps`` evaluations
+    of ``nloc`` light curves.  Single light curve (fused sweep): the tiles run in all three launch kinds of the chain -- filler
+    workgroups of the k_diag launches, the tail of the k_trsm grids, k_update_rows -- so the achieved rate is taken over ALL
+    sweep launches (the diagonal-block and row-solve work inside them included in the time); batches (panel sweep): over the
+    k_update launches."""
+    fused_ms, fused_launches = prof.get("diag_block+trailing_update", (0.0, 0))
+    upd_ms, upd_launches = prof["trailing_update"]
+    flops = update_flops(n) * nloc * steps
+    launch_mix, early_products = None, 0
+    if fused_launches:
+        trsm_ms, trsm_launches = prof["row_solve"]
+        diag_ms, diag_launches = prof["diag_block"]
+        flops += trsm_flops(n, need_grad=True) * nloc * steps
+        early_products = ws.early_inverse_products()          # (inverse-pass products that ran as fillers inside these launches)
+        flops += early_products * 2.0 * NB ** 3 * steps
+        launch_mix = {"k_diag": round((fused_ms + diag_ms) / max(fused_launches + diag_launches, 1) * 1e3, 2),
+                      "k_trsm": round(trsm_ms / max(trsm_launches, 1) * 1e3, 2),
+                      "k_update_rows": round(upd_ms / max(upd_launches, 1) * 1e3, 2)}
+        upd_ms += fused_ms + diag_ms + trsm_ms
+        upd_launches += fused_launches + diag_launches + trsm_launches
+    achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+    traffic, traffic_src = measured_traffic(bool(fused_launches)) if (n == 4096 and nloc == 1) else (None, None)
+    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles incl. early inverse-pass products; k_trsm: row solve + update tiles; "
+             "k_update_rows): trailing-update + row-solve tile GEMM"
+             if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN"
+    roofline = dict(bound="mfma", kernel=kname,
+                    achieved=round(achieved, 3), peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                    avg_launch_us=round(upd_ms / max(upd_launches, 1) * 1e3, 2), launches_per_eval=upd_launches // max(steps, 1),
+                    flops_per_eval=flops / max(steps, 1))
+    if launch_mix:
+        roofline["avg_launch_us_by_kernel"] = launch_mix
+        roofline["early_inverse_products_per_eval"] = early_products
+    return roofline
+
+
+def build_roofline(prof, n, nloc):
+    """The HBM-bound stage of the path: the kernel build streams the upper block triangle of A out once (8 N^2 / 2 bytes at
+    tile granularity; it is in fact bound by the Q N^2 / 2 fp64 exp it evaluates)."""
+    nbk = (n + NB - 1) // NB
+    build_ms, build_launches = prof["sm_build"]
+    build_bytes = 8.0 * NB * NB * (nbk * (nbk + 1) // 2) * nloc
+    gbs = build_bytes * build_launches / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
+    return dict(bound="hbm", kernel="k_build (spectral-mixture kernel matrix, upper block triangle)", achieved=round(gbs, 1),
+                peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4), avg_launch_us=round(build_ms / max(build_launches, 1) * 1e3, 2),
+                bytes_per_launch=build_bytes)
+
+
+class Harness:
+    """Barrier + synchronize on both sides of exactly K timed steps, MAX over ranks."""
+
+    def __init__(self, dev, world):
+        self.dev, self.world = dev, world
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def time(self, step, steps, warmup):
+        res = None
+        for _ in range(warmup):
+            res = step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        self.fence()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), res
+
+
+def strong_scaling_run(h, total, n, steps, warmup, rank, world, dev, chunk=None, profile=True):
+    """One ``total``-light-curve batch (config-3 recipe) evaluated by all ranks together: block partition, chunked batched
+    evaluation per rank, one all_gather of the log-likelihoods per step."""
+    counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    nloc = counts[rank]
+    chunk = chunk or default_chunk(n)
+    shard = make_shard(total, rank, world, n, "cfg3", dev)
+    ws = _hip.get_workspace(dev, n, 4, 1, max(1, min(chunk, nloc)))
+    step = lambda: sharded_batch_step(shard, total, chunk)
+    if warmup == 0 and nloc:
+        # no untimed full pass (it would cost as much as the measurement): the launch sequences of the two chunk shapes are
+        # captured on one chunk each instead
+        for lo, hi in sorted({(0, min(chunk, nloc)), (nloc - ((nloc % chunk) or min(chunk, nloc)), nloc)}):
+            sharded_batch_step({k: v[lo:hi] for k, v in shard.items()}, hi - lo, chunk, group=False)
+    elapsed, (out, ll) = h.time(step, steps, warmup)
+    assert nloc == 0 or int(out["info"].abs().max()) == 0, "factorisation failed inside the timed region"
+    assert ll.numel() == total and bool(torch.isfinite(ll).all())
+    tfl = float(n) ** 3 * total * steps / elapsed / world / 1e12
+    res = dict(total_batch=total, n=n, steps=steps, warmup=warmup, evals_per_s=round(total * steps / elapsed, 3),
+               ms_per_step=round(elapsed / steps * 1e3, 4), light_curves_per_gpu=counts, chunk=chunk,
+               algorithmic_tflops_per_gpu=round(tfl, 3), algorithmic_frac_of_fp64_mfma_peak=round(tfl / FP64_MATRIX_PEAK_TFLOPS, 4),
+               loglik_checksum=float(ll.sum()))
+    prof = None
+    if profile and nloc:
+        ws.profile(True)
+        step()
+        prof = ws.profile_read()
+        ws.profile(False)
+    return res, prof, ws, nloc, (float(ll[0]) if total else None)
 
 
 def main():
@@ -93,11 +254,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="light curves per GPU per step")
+    ap.add_argument("--batch", type=int, default=1, help="weak scaling: light curves per GPU per step")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: light curves of the whole batch, sharded over the GPUs")
+    ap.add_argument("--chunk", type=int, default=0, help="strong scaling: light curves per launch set (0: by memory, at most 64)")
     ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the batched / surface side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the batched / strong-scaling side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,35 +275,52 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    h = Harness(dev, world)
+    n = args.n
+    metric = "marginal-log-likelihood evals/sec, N=4096 Q=4 SM kernel" if n == 4096 else f"marginal-log-likelihood evals/sec, N={n} Q=4 SM kernel"
 
-    n, B = args.n, args.batch
+    if args.total_batch > 0:
+        # ---------------- strong scaling: one batch, all ranks
+        total = args.total_batch
+        res, prof, ws, nloc, first = strong_scaling_run(h, total, n, args.steps, args.warmup, rank, world, dev, args.chunk or None)
+        if rank == 0:
+            result = {
+                "metric": metric, "value": res["evals_per_s"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"cfg3-style batch: {total} independent 1-D light curves N={n}, Q=4 spectral-mixture exact GP, fp64, "
+                                       f"value + full gradient, the whole batch per step", "total_batch": total, "n": n, "q": 4, "d": 1,
+                           "light_curves_per_gpu": res["light_curves_per_gpu"], "chunk": res["chunk"],
+                           "parallelism": f"block partition of the batch over {world} GPU(s), one all_gather of the {total} log-liks per step"},
+                "whole_evaluation": {"algorithmic_flops_per_eval": float(n) ** 3, "tflops_per_gpu": res["algorithmic_tflops_per_gpu"],
+                                     "frac_of_fp64_mfma_peak": res["algorithmic_frac_of_fp64_mfma_peak"]},
+            }
+            if prof is not None:                                  # one profiled pass of rank 0's shard
+                result["roofline"] = sweep_roofline(prof, ws, n, nloc, 1)
+                result["roofline_build"] = build_roofline(prof, n, min(nloc, res["chunk"]))
+                result["phase_ms_per_step"] = {k: round(v[0], 4) for k, v in prof.items()}
+            if world == 1 and not args.no_cpu:
+                cb, cpu_val = cpu_baseline(n, args.cpu_reps, "cfg3")
+                result["cpu_baseline"] = cb
+                result["parity"] = {"abs_dmll_vs_cpu_oracle": abs(first - cpu_val), "tolerance": 1e-4, "mll": first}
+                result["speedup_vs_cpu_baseline"] = round(res["evals_per_s"] / cb["value"], 1)
+            print(json.dumps(result))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- headline: weak scaling, B light curves per GPU per step
+    B = args.batch
     data = make_batch(n, B, rank, dev)
     ws = _hip.get_workspace(dev, n, 4, 1, B)
 
-    def step(check=False):
+    def step():
         out = _hip.mll_value_grad(data["x"], data["y"], data["mean"], data["noise"], None, data["w"], data["mu"], data["v"],
                                   0, 0.0, True, workspace=ws)
         ll = gather_logliks(out["mll"], B * world)
         return out, ll
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out, ll = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, ll = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
+    elapsed, (out, ll) = h.time(step, args.steps, args.warmup)
     assert int(out["info"].abs().max()) == 0, "factorisation failed inside the timed region"
     assert ll.numel() == B * world and bool(torch.isfinite(ll).all())
     ms_per_step = elapsed / args.steps * 1e3
@@ -152,65 +332,14 @@ def main():
         step()
     prof = ws.profile_read()
     ws.profile(False)
-    # The dominant kernel is the tile GEMM of the factorisation sweep (trailing update 2N^3/3 flop per evaluation, plus
-    # the row solves).  For a single light curve (fused sweep) its tiles run in all three launch kinds of the chain --
-    # filler workgroups of the k_diag launches, the tail of the k_trsm grids, k_update_rows -- so the achieved rate is
-    # taken over ALL sweep launches (the diagonal-block and row-solve work inside them included in the time); in
-    # panel mode (batches, big N) over the k_update launches as before.
-    fused_ms, fused_launches = prof.get("diag_block+trailing_update", (0.0, 0))
-    upd_ms, upd_launches = prof["trailing_update"]
-    flops = update_flops(n) * B * args.steps
-    launch_mix = None
-    if fused_launches:
-        trsm_ms, trsm_launches = prof["row_solve"]
-        diag_ms, diag_launches = prof["diag_block"]
-        flops += trsm_flops(n, need_grad=True) * B * args.steps
-        # (products of the inverse pass that ran as filler workgroups inside these launches count with them)
-        early_products = ws.early_inverse_products()
-        flops += early_products * 2.0 * NB ** 3 * args.steps
-        launch_mix = {"k_diag": round((fused_ms + diag_ms) / max(fused_launches + diag_launches, 1) * 1e3, 2),
-                      "k_trsm": round(trsm_ms / max(trsm_launches, 1) * 1e3, 2),
-                      "k_update_rows": round(upd_ms / max(upd_launches, 1) * 1e3, 2)}
-        upd_ms += fused_ms + diag_ms + trsm_ms
-        upd_launches += fused_launches + diag_launches + trsm_launches
-    achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-    # memory-side bytes per launch: not measurable from inside the process; taken from the committed
-    # rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH x2 for gfx950; tools/pmc_traffic.py)
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", PMC_FILE)
-    if n == 4096 and B == 1 and os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        rows = [v for k, v in pmc.items() if k.startswith("k_update") or (fused_launches and (k.startswith("k_diag") or k.startswith("k_trsm")))]
-        tot_l = sum(r["launches"] for r in rows)
-        if tot_l:
-            traffic = sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot_l
-            traffic_src = f"profiles/{PMC_FILE} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, same workload, earlier run)"
-    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles incl. early inverse-pass products; k_trsm: row solve + update tiles; "
-             "k_update_rows): trailing-update + row-solve tile GEMM"
-             if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN"
-    roofline = dict(bound="mfma", kernel=kname,
-                    achieved=round(achieved, 3), peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / FP64_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
-                    avg_launch_us=round(upd_ms / max(upd_launches, 1) * 1e3, 2), launches_per_eval=upd_launches // args.steps,
-                    flops_per_eval=flops / args.steps)
-    if launch_mix:
-        roofline["avg_launch_us_by_kernel"] = launch_mix
-        roofline["early_inverse_products_per_eval"] = early_products
-    # the HBM-bound stage of the path: the kernel build streams the upper block triangle of A out once (8 N^2 / 2 bytes
-    # at tile granularity; it is in fact bound by the Q N^2 / 2 fp64 exp it evaluates)
-    nbk = (n + NB - 1) // NB
-    build_ms, build_launches = prof["sm_build"]
-    build_bytes = 8.0 * NB * NB * (nbk * (nbk + 1) // 2) * B
-    build_gbs = build_bytes * build_launches / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
-    roofline_build = dict(bound="hbm", kernel="k_build (spectral-mixture kernel matrix, upper block triangle)", achieved=round(build_gbs, 1),
-                          peak=8000.0, unit="GB/s", frac=round(build_gbs / 8000.0, 4), avg_launch_us=round(build_ms / max(build_launches, 1) * 1e3, 2),
-                          bytes_per_launch=build_bytes)
+    roofline = sweep_roofline(prof, ws, n, B, args.steps)
+    roofline_build = build_roofline(prof, n, B)
     phases = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
 
     result = None
     if rank == 0:
         result = {
-            "metric": "marginal-log-likelihood evals/sec, N=4096 Q=4 SM kernel" if n == 4096 else f"marginal-log-likelihood evals/sec, N={n} Q=4 SM kernel",
+            "metric": metric,
             "value": round(value, 3), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -246,7 +375,14 @@ def main():
         extra["batched"] = {"batch_per_gpu": B2, "evals_per_s": round(B2 * k2 / bt, 3),
                             "trailing_update_tflops": round(update_flops(n) * B2 * 2 / (u2 * 1e-3) / 1e12, 2) if u2 > 0 else None,
                             "trailing_update_frac": round(update_flops(n) * B2 * 2 / (u2 * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 4) if u2 > 0 else None}
-        ws = _hip.get_workspace(dev, n, 4, 1, B)
+        del d2, ws2
+    if not args.no_extra:
+        # strong scaling beside the headline (at every world size, so that the driver's N=1,2,4,8 runs record it): BASELINE
+        # configs[2] (512 x N=2048) and the north_star's 4096-light-curve batch at the headline size; the whole batch per step
+        ss = {}
+        for tag, total, nn, k, w in (("cfg3_512_x_n2048", 512, 2048, 3, 1), ("batch4096_x_n4096", 4096, 4096, 1, 0)):
+            ss[tag] = strong_scaling_run(h, total, nn, k, w, rank, world, dev, None, profile=False)[0]
+        extra["strong_scaling"] = ss
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, cpu_val = cpu_baseline(n, args.cpu_reps)
         result["cpu_baseline"] = cb

@@ -26,8 +26,9 @@ end -- enough to swap the order of two near-equal peaks.
 reference's own ``fit_LS`` on the astropy-shaped shim): the comparison notebook's initial frequencies (0.0067,
 0.0154); the Lomb-Scargle notebook's five 1-D peaks to the 6 printed digits with their significance flags
 (``docs/source/notebooks/PGMUVI_Lomb_Scargle.ipynb`` cells 10/12/34: exact sums give the same five peaks with the
-4th and 5th swapped -- their powers are 0.3913 and 0.3910 --, ``power_fast`` gives the recorded order, i.e. the
-'davies' / 'single' false-alarm formulas and the Benjamini-Hochberg step decide as recorded); the
+4th and 5th swapped -- their powers are 0.3913 and 0.3910 --, ``power_fast`` gives the recorded order; the flags come
+from the reference's own phase-scramble bootstrap over the periodogram, because a band selected from a 2-D light curve
+stays on the multiband code path -- the analytic 'davies' / 'baluev' / 'single' formulas below remain unverified); the
 ``use_best_band_init=True`` periodogram's peak period / height / prominence (149.170715 / 0.992789 / 0.859738, cell 20).
 **Not reproduced**: the *default multiband* numbers of that cell (height 0.909449, prominence 0.579050): the
 chi^2-weighted "fast" multiband form restated in ``multiband_fast`` gives 0.984977 / 0.824881, and so do a restated

@@ -121,6 +121,7 @@ class Workspace:
         _check(lib.pgm_workspace_create(byref(handle), idx, max_n, max_q, max_d, max_batch), "pgm_workspace_create")
         self.handle = handle
         self.max_n, self.max_q, self.max_d, self.max_batch = max_n, max_q, max_d, max_batch
+        self.nominal_bytes = int(lib.pgm_workspace_bytes(handle))       # at creation; R and prediction scratch grow on first use
 
     @property
     def bytes(self) -> int:
@@ -155,28 +156,53 @@ class Workspace:
         return int(load().pgm_profile_early_inverse_products(self.handle))
 
 
-_workspaces: Dict[tuple, Workspace] = {}
+# Cache of workspaces, least recently used first.  A request is served by ANY cached workspace that covers it (the C side
+# takes n <= max_n, q d <= max_q max_d, d <= max_d, batch <= max_batch), the smallest such; a miss allocates an exact fit and
+# then drops least-recently-used entries from the cache until it is back under the byte budget.  Dropping never frees: the
+# device buffers go when the last holder lets go of the Workspace object (a NativeFit, the dictionary an evaluation
+# returned, a captured graph's owner ...), so raw addresses baked into graphs and handles stay valid for as long as
+# anything can still use them.
+_workspaces: "Dict[tuple, Workspace]" = {}
+_ws_lock = threading.RLock()                       # (not ``_lock``: creating a Workspace calls load(), which takes that one)
+WORKSPACE_BUDGET_BYTES = int(float(os.environ.get("PGMUVI_WORKSPACE_BUDGET_GB", "128")) * (1 << 30))
+
+
+def _covers(ws: "Workspace", idx: int, np_: int, q: int, d: int, batch: int) -> bool:
+    return (ws.handle is not None and ws.key[0] == idx and ws.max_n >= np_ and ws.max_d >= d and ws.max_q * ws.max_d >= q * d
+            and ws.max_batch >= batch)
 
 
 def get_workspace(device, n: int, q: int, d: int, batch: int = 1) -> Workspace:
-    """Cached workspace large enough for (n, q, d, batch) on `device` (sizes round up
-    so that a fit loop with fixed shapes allocates once)."""
+    """Cached workspace large enough for (n, q, d, batch) on `device` (n rounds up to the 128-block, so that a fit loop
+    with fixed shapes allocates once; alternating shapes -- SM and dense back-end, the tail chunk of a batch, a second
+    model -- reuse what is there instead of reallocating)."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     np_ = (n + 127) // 128 * 128
-    key = (idx, np_, q, d, batch)
-    ws = _workspaces.get(key)
-    if ws is None:
-        for k in [k for k in _workspaces if k[0] == idx and k != key]:
-            _workspaces.pop(k).close()          # one live workspace per device: they are big
-        ws = Workspace(torch.device("cuda", idx), np_, q, d, batch)
-        _workspaces[key] = ws
-    return ws
+    with _ws_lock:
+        best = None
+        for key, ws in _workspaces.items():
+            if _covers(ws, idx, np_, q, d, batch) and (best is None or ws.nominal_bytes < _workspaces[best].nominal_bytes):
+                best = key
+        if best is not None:
+            ws = _workspaces.pop(best)
+            _workspaces[best] = ws                      # most recently used last
+            return ws
+        with torch.cuda.device(idx):
+            ws = Workspace(torch.device("cuda", idx), np_, q, d, batch)
+        _workspaces[ws.key] = ws
+        total = sum(w.nominal_bytes for w in _workspaces.values())
+        for key in list(_workspaces):
+            if total <= WORKSPACE_BUDGET_BYTES or key == ws.key:
+                continue
+            total -= _workspaces.pop(key).nominal_bytes  # (freed when its last holder drops it)
+        return ws
 
 
 def release_workspaces():
-    for k in list(_workspaces):
-        _workspaces.pop(k).close()
+    """Empties the cache (buffers are freed as soon as nothing else holds the Workspace objects)."""
+    with _ws_lock:
+        _workspaces.clear()
 
 
 def current_stream_ptr(device) -> c_void_p:

@@ -58,6 +58,56 @@ def evaluate_batch(x, y, mean, noise, w, mu, v, noise_scalar=None, dim_order=0, 
     return {k: torch.cat([o[k] for o in outs]) for k in keys}
 
 
+def make_shard(total: int, rank: int, world: int, n: int, recipe: str = "cfg3", device=None) -> Dict[str, torch.Tensor]:
+    """This rank's contiguous block of a synthetic ``total``-light-curve batch: light curve i of the
+    batch depends on (recipe, i, n) only -- never on the partition -- so any world size evaluates the same ``total`` problems.
+    ``recipe`` "cfg3": leading period ~ U(30, 300) per light curve (BASELINE config 3); "cfg2": config 2's periods, seed 2 + i."""
+    from . import synthetic as syn
+    lo, hi = shard_bounds(total, rank, world)
+    cols = {k: [] for k in ("x", "y", "mean", "noise", "w", "mu", "v")}
+    for i in range(lo, hi):
+        if recipe == "cfg3":
+            (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=n)
+            h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        else:
+            t, y, e = syn.cfg2(n_obs=n, seed=2 + i)
+            h = syn.cfg_hypers(2, y.double())
+        q = h["w"].numel()
+        cols["x"].append(t.double().reshape(n, 1)); cols["y"].append(y.double()); cols["noise"].append(e.double() ** 2)
+        cols["mean"].append(h["mean"].expand(n)); cols["w"].append(h["w"])
+        cols["mu"].append(h["mu"].reshape(q, 1)); cols["v"].append(h["v"].reshape(q, 1))
+    if lo == hi:                                                  # more ranks than light curves: an empty shard of the right shapes
+        z = lambda *s: torch.zeros(s, dtype=torch.float64)
+        out = dict(x=z(0, n, 1), y=z(0, n), mean=z(0, n), noise=z(0, n), w=z(0, 4), mu=z(0, 4, 1), v=z(0, 4, 1))
+    else:
+        out = {k: torch.stack(v).contiguous() for k, v in cols.items()}
+    return out if device is None else {k: v.to(device) for k, v in out.items()}
+
+
+def default_chunk(n: int, budget_bytes: float = 16e9) -> int:
+    """Light curves per launch set of a shard: as many as fit ``budget_bytes`` of workspace (8 N^2 bytes each and ~15 % of
+    side buffers), at most 64 -- beyond that the launches are long enough that nothing is gained."""
+    np_ = (n + 127) // 128 * 128
+    return int(max(1, min(64, budget_bytes // (9.2 * np_ * np_))))
+
+
+def sharded_batch_step(shard: Dict[str, torch.Tensor], total: int, chunk: Optional[int] = None, need_grad=True, group=None,
+                       _compute=None) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+    """One evaluation of a ``total``-light-curve batch whose local block is ``shard`` (see :func:`make_shard`): the shard in
+    memory-bounded chunks through the batched entry point, then ONE all_gather of the log-likelihoods (RCCL on GPUs).  Returns
+    (local outputs, the length-``total`` log-likelihood vector, identical on every rank)."""
+    nloc = shard["y"].shape[0]
+    if nloc:
+        out = evaluate_batch(shard["x"], shard["y"], shard["mean"], shard["noise"], shard["w"], shard["mu"], shard["v"],
+                             need_grad=need_grad, chunk=chunk or default_chunk(shard["y"].shape[1]), _compute=_compute)
+    else:
+        out = dict(mll=torch.zeros(0, dtype=torch.float64, device=shard["y"].device),
+                   info=torch.zeros(0, dtype=torch.int32, device=shard["y"].device))
+    if group is False:                                           # local only (warm-up of a chunk shape): no collective
+        return out, out["mll"]
+    return out, gather_logliks(out["mll"], total, group=group)
+
+
 def gather_logliks(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """all_gather of the per-curve values of every rank's shard (block partition) into
     one length-``total`` vector, identical on every rank.  Single process: identity."""

@@ -1066,10 +1066,16 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   const int bad = P.info[b];
   // workgroup 0: the scalars (mll, hyper-parameter gradients); workgroups 1..: the per-point gradients
   // (mean and noise), FIN_THREADS points each -- side by side instead of one after the other
+  // (a failed factorisation leaves NaN in every output, so that no caller steps on the previous evaluation's gradients)
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   if (blockIdx.x > 0) {
-    if (!P.need_grad || bad) return;
+    if (!P.need_grad) return;
     const double half_n = 0.5 / (double)P.n;
     const int i = ((int)blockIdx.x - 1) * FIN_THREADS + t;
+    if (bad) {
+      if (i < P.n) { P.out_gmean[b * P.sVec + i] = qnan; P.out_gnoise[b * P.sVec + i] = qnan; }
+      return;
+    }
     if (i < P.n) {
       const double al = P.alpha[b * P.sVec + i];
       P.out_gmean[b * P.sVec + i] = al / (double)P.n;
@@ -1089,10 +1095,13 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   if (t == 0) {
     double tot = 0.0;
     for (int wv = 0; wv < FIN_THREADS / 64; ++wv) tot += red[wv];
-    const double nan = __longlong_as_double(0x7ff8000000000000LL);
-    P.out_small[b * P.sOut + 0] = bad ? nan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
+    P.out_small[b * P.sOut + 0] = bad ? qnan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
   }
-  if (!P.need_grad || bad) return;
+  if (!P.need_grad) return;
+  if (bad) {
+    if (t >= 1 && t < 1 + P.q + 2 * P.qd) P.out_small[b * P.sOut + t] = qnan;
+    return;
+  }
   const double half_n = 0.5 / (double)P.n;
   const int Q = P.q, QD = P.qd;
   const double* hyp = P.hyp + (int64_t)b * (PGM_MAX_QD * 3);
@@ -1519,7 +1528,11 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
   __syncthreads();
   for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
   const double lp_sum = red[0];
-  if (t < F.P && it < F.max_iter) {
+  // a failed factorisation (NaN value and gradients): the step is skipped -- parameters and moments stay as they are, the
+  // log holds the NaN loss for the host to find at its next read
+  const bool ok = isfinite(mll[0]);
+  if (t < F.P && it < F.max_iter && !ok) F.raw_hist[(int64_t)it * F.P + t] = F.raw[t];
+  if (t < F.P && it < F.max_iter && ok) {
     const int p = t, o = F.nmean;
     double gth;                                             // d(-mll)/d theta_p
     if (p < o) gth = -sums[p];

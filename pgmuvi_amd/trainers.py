@@ -287,35 +287,18 @@ def _prior_descriptor(model, likelihood, pieces, noise_mod):
     return (kind, loc, scale) if found else None
 
 
-def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10, stop=None,
-                 lr=1e-4, lossfn="mll", optim="SGD", eps=1e-8, stopavg=9, check_every=25, **kwargs):
-    """:func:`train` with the whole optimiser loop on the device (``pgm_fit_*``, SURVEY.md section 8f row 2): constraint
-    transforms, evaluation, chain rule, SGD / Adam / AdamW step and the loss / parameter log are one hipGraph replay per
-    iteration; the host only reads the log every ``check_every`` iterations for the stop rule of ``pgmuvi/trainers.py:200-207``.
-    For constant- or linear-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood, with or
-    without plain Normal / LogNormal priors on those parameters (MAP, the priors ``set_default_priors`` registers); anything
-    else raises ``NotImplementedError`` (use :func:`train_device`).  Same ``results`` as :func:`train`; the model's raw
-    parameters hold the final values afterwards."""
+def _native_fit_handle(model, likelihood, train_x, train_y, maxiter, lr, optim, eps=1e-8):
+    """The ``pgm_fit`` handle of a model (constraint / prior tables, raw start vector) and where each piece of the raw vector
+    lives in the model: (fit, pieces, raw0).  Raises ``NotImplementedError`` for models outside the native loop's scope."""
     from . import _hip
     from .gpytorch import kernels, likelihoods, means
-    from .gpytorch.utils.errors import NanError
-    if lightcurve is not None:
-        model, likelihood = lightcurve.model, lightcurve.likelihood
-        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
-    elif any(v is None for v in (model, likelihood, train_x, train_y)):
-        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
-                         "and train_y **must** be passed to train().")
-    if lossfn != "mll":
-        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
-    if optim not in _hip.NativeFit.OPT:
-        raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the native loop.")
     k = getattr(model, "covar_module", None)
     mm = getattr(model, "mean_module", None)
     linear = type(mm) is means.LinearMean
     if not isinstance(k, kernels.SpectralMixtureKernel) or not (type(mm) is means.ConstantMean or (linear and mm.bias is not None)):
         raise NotImplementedError("train_native handles Constant/LinearMean + SpectralMixtureKernel models; use train_device")
     model.train(); likelihood.train()
-    Q, d = k.num_mixtures, k.ard_num_dims
+    Q = k.num_mixtures
     if isinstance(likelihood, likelihoods.FixedNoiseGaussianLikelihood):
         if getattr(likelihood, "second_noise_covar", None) is not None:
             raise NotImplementedError("learn_additional_noise is not handled by train_native; use train_device")
@@ -343,6 +326,75 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                          [t[2] for t in desc], noise_mod is not None, optim, lr, (0.9, 0.999), eps, wd, maxiter, linear_mean=linear)
     if prior_tab is not None:
         fit.set_priors(*prior_tab)
+    return fit, pieces, raw0
+
+
+def _lightcurve_traces(lightcurve, pieces, hist):
+    """Per-iteration values of every ``Lightcurve.get_parameters()`` key (``pgmuvi/lightcurve.py:8999-9077``) from the raw
+    history of the native loop: without data transforms the constrained values of all iterations come from one vectorised
+    constraint transform per parameter; with ``xtransform`` / ``ytransform`` set each row goes through ``get_parameters``."""
+    n_keep = hist.shape[0]
+    model = lightcurve.model
+    where, off = {}, 0
+    for mod, name in pieces:
+        p = getattr(mod, name)
+        where[id(p)] = (off, p.numel(), tuple(p.shape), mod, name, p)
+        off += p.numel()
+    traces = {}
+    plain = getattr(lightcurve, "xtransform", None) is None and getattr(lightcurve, "ytransform", None) is None
+    if plain:
+        for pname, p in model.named_parameters():
+            o, cnt, shp, mod, name, _ = where[id(p)]
+            rows = torch.as_tensor(hist[:, o:o + cnt]).to(p.dtype).reshape((n_keep,) + shp)     # (the model's dtype, as get_parameters sees it)
+            if "raw" in pname:
+                key = ".".join(c.lstrip("raw_") for c in pname.split("."))             # (the reference's own key rule)
+                con = getattr(mod, "_constraints", {}).get(name + "_constraint")
+                vals = rows if con is None else con.transform(rows)
+            else:
+                key, vals = pname, rows
+            arr = vals.detach().cpu().numpy()
+            traces[key] = [arr[i] for i in range(n_keep)]
+        return traces
+    keep = {id(v[5]): v[5].detach().clone() for v in where.values()}
+    try:
+        for i in range(n_keep):
+            with torch.no_grad():
+                for o, cnt, shp, _, _, p in where.values():
+                    p.copy_(torch.as_tensor(hist[i, o:o + cnt], dtype=p.dtype).reshape(shp).to(p.device))
+            for key, value in lightcurve.get_parameters().items():
+                traces.setdefault(key, []).append(value.cpu().detach().numpy())
+    finally:
+        with torch.no_grad():
+            for _, _, _, _, _, p in where.values():
+                p.copy_(keep[id(p)])
+    return traces
+
+
+def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10, stop=None,
+                 lr=1e-4, lossfn="mll", optim="SGD", eps=1e-8, stopavg=9, check_every=25, **kwargs):
+    """:func:`train` with the whole optimiser loop on the device (``pgm_fit_*``, SURVEY.md section 8f row 2): constraint
+    transforms, evaluation, chain rule, SGD / Adam / AdamW step and the loss / parameter log are one hipGraph replay per
+    iteration; the host only reads the log every ``check_every`` iterations for the stop rule of ``pgmuvi/trainers.py:200-207``.
+    For constant- or linear-mean spectral-mixture exact GPs with a fixed-noise or learned-scalar-noise Gaussian likelihood, with or
+    without plain Normal / LogNormal priors on those parameters (MAP, the priors ``set_default_priors`` registers); anything
+    else raises ``NotImplementedError`` (use :func:`train_device`).  Same ``results`` as :func:`train` -- one entry per
+    iteration for the loss and for every parameter key, in lightcurve mode the keys and values of ``get_parameters()`` --;
+    the model's raw parameters hold the final values afterwards.  A failed factorisation skips its step on the device (no
+    parameter or moment is touched by NaN gradients) and surfaces as ``NanError`` at the next read of the log, with the last
+    good parameters in the model."""
+    from . import _hip
+    from .gpytorch.utils.errors import NanError
+    if lightcurve is not None:
+        model, likelihood = lightcurve.model, lightcurve.likelihood
+        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
+    elif any(v is None for v in (model, likelihood, train_x, train_y)):
+        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
+                         "and train_y **must** be passed to train().")
+    if lossfn != "mll":
+        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
+    if optim not in _hip.NativeFit.OPT:
+        raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the native loop.")
+    fit, pieces, raw0 = _native_fit_handle(model, likelihood, train_x, train_y, maxiter, lr, optim, eps)
     results = {"loss": [], "delta_loss": []}
     names = [n_ for n_, _ in model.named_parameters()]
     if lightcurve is not None:
@@ -352,7 +404,17 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
         for n_ in names:
             results[n_.split(".")[1] if "raw" in n_ else n_] = []
             results.setdefault(n_, [])
+
+    def write_back(row):
+        off = 0
+        for mod, name in pieces:
+            p = getattr(mod, name)
+            with torch.no_grad():
+                p.copy_(torch.as_tensor(row[off:off + p.numel()], dtype=p.dtype).reshape(p.shape).to(p.device))
+            off += p.numel()
+
     done, stopped = 0, False
+    hist = np.zeros((0, len(raw0)))
     try:
         while done < maxiter and not stopped:
             blk = min(check_every, maxiter - done)
@@ -360,6 +422,8 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
             k_done, losses, hist, raw, info = fit.read()
             new = losses[done:k_done]
             if info != 0 or not np.isfinite(new).all():
+                good = int(np.argmax(~np.isfinite(losses[:k_done]))) if not np.isfinite(losses[:k_done]).all() else k_done
+                write_back(hist[good - 1] if good > 0 else np.asarray(raw0))           # the last parameters a finite loss produced
                 raise NanError("non-finite loss in the native loop (factorisation failed or NaN parameters)")
             for off, value in enumerate(new):
                 i = done + off
@@ -373,23 +437,21 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                     break
             done = k_done
         n_keep = len(results["loss"])
-        final = hist[n_keep - 1] if n_keep > 0 else np.asarray(raw0)
-        # write the parameters of the last logged iteration back into the model, and the per-iteration history
-        off = 0
-        offsets = {}
-        for mod, name in pieces:
-            p = getattr(mod, name)
-            with torch.no_grad():
-                p.copy_(torch.as_tensor(final[off:off + p.numel()], dtype=p.dtype).reshape(p.shape).to(p.device))
-            offsets[id(p)] = (off, p.numel(), tuple(p.shape))
-            off += p.numel()
+        # the parameters of the last logged iteration go back into the model, the per-iteration history into the results
+        write_back(hist[n_keep - 1] if n_keep > 0 else np.asarray(raw0))
         if lightcurve is None:
+            off = 0
+            offsets = {}
+            for mod, name in pieces:
+                p = getattr(mod, name)
+                offsets[id(p)] = (off, p.numel(), tuple(p.shape))
+                off += p.numel()
             for n_, p in model.named_parameters():
                 o, cnt, shp = offsets[id(p)]
                 results[n_].extend([hist[i, o:o + cnt].reshape(shp).copy() for i in range(n_keep)])
         else:
-            for key, value in lightcurve.get_parameters().items():
-                results[key].append(value.cpu().detach().numpy())
+            for key, rows in _lightcurve_traces(lightcurve, pieces, hist[:n_keep]).items():
+                results[key].extend(rows)
     finally:
         fit.close()
     return results

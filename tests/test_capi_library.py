@@ -51,3 +51,45 @@ def test_code_object_is_gfx950_only():
     assert b"gfx950" in blob
     for other in (b"gfx942", b"gfx90a", b"sm_90", b"nvptx"):
         assert other not in blob
+
+
+def test_workspace_cache_policy_without_a_gpu(monkeypatch):
+    """``_hip.get_workspace``: a request is served by the smallest cached workspace that covers it; a miss allocates an exact
+    fit; going over the byte budget only DROPS least-recently-used entries from the cache (their buffers live on for whoever
+    still holds them -- a native fit, a captured graph) and never closes a handle."""
+    from pgmuvi_amd import _hip
+
+    class FakeWorkspace:
+        made, closed = [], []
+
+        def __init__(self, device, max_n, max_q, max_d, max_batch=1):
+            _hip.load()                                        # (the real constructor takes the loader's lock: must not deadlock)
+            self.key = (0, max_n, max_q, max_d, max_batch)
+            self.max_n, self.max_q, self.max_d, self.max_batch = max_n, max_q, max_d, max_batch
+            self.handle = object()
+            self.nominal_bytes = 8 * max_n * max_n * max_batch
+            FakeWorkspace.made.append(self)
+
+        def close(self):
+            FakeWorkspace.closed.append(self)
+            self.handle = None
+
+    import contextlib
+    monkeypatch.setattr(_hip, "Workspace", FakeWorkspace)
+    monkeypatch.setattr(_hip.torch.cuda, "device", lambda idx: contextlib.nullcontext())
+    monkeypatch.setattr(_hip, "_workspaces", {})
+    monkeypatch.setattr(_hip, "WORKSPACE_BUDGET_BYTES", 8 * 2048 * 2048 * 5)
+    dev = "cuda:0"
+    a = _hip.get_workspace(dev, 2000, 4, 1, 4)                 # 2048-point blocks, batch 4
+    assert a.max_n == 2048 and _hip.get_workspace(dev, 2048, 4, 1, 4) is a
+    assert _hip.get_workspace(dev, 100, 1, 1, 1) is a and _hip.get_workspace(dev, 1000, 2, 1, 3) is a
+    b = _hip.get_workspace(dev, 1000, 2, 2, 1)                 # d = 2 is not covered by a (max_d 1): a second, small workspace
+    assert b is not a and b.max_d == 2 and len(FakeWorkspace.made) == 2
+    assert _hip.get_workspace(dev, 900, 1, 1, 1) is b          # the smallest that covers
+    c = _hip.get_workspace(dev, 2048, 4, 1, 5)                 # batch 5 > 4: a third; 4 + 5 batches of 2048^2 exceed the budget of 5
+    assert c is not a and len(FakeWorkspace.made) == 3
+    assert a not in _hip._workspaces.values() and c in _hip._workspaces.values()       # the least recently used went
+    assert FakeWorkspace.closed == [] and a.handle is not None                          # ... out of the cache only
+    assert _hip.get_workspace(dev, 2000, 4, 1, 4) is c
+    _hip.release_workspaces()
+    assert _hip._workspaces == {} and FakeWorkspace.closed == []

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from pgmuvi_amd import synthetic as syn  # noqa: E402
-from pgmuvi_amd.batch import balanced_assignment, evaluate_batch, gather_logliks, shard_bounds  # noqa: E402
+from pgmuvi_amd.batch import (balanced_assignment, default_chunk, evaluate_batch, gather_logliks, make_shard,  # noqa: E402
+                              shard_bounds, sharded_batch_step)
 
 B, N = 5, 40
 
@@ -66,6 +67,50 @@ def test_world_size_2_shard_and_gather_equals_single_process():
     for rank, ll, gw in got:
         assert ll.shape == (B,) and torch.equal(ll, full["mll"])       # every rank holds the whole vector
         assert torch.equal(gw, full["g_w"])
+
+
+def _strong_worker(rank, world, port, q, total, n, chunk):
+    """The code path of ``bench.py --total-batch`` (``make_shard`` + ``sharded_batch_step``) with the oracle stand-in."""
+    import _oracle_backend as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = make_shard(total, rank, world, n, "cfg3")
+    out, ll = sharded_batch_step(shard, total, chunk, _compute=ob.mll_value_grad)
+    q.put((rank, shard["y"].shape[0], ll, out.get("g_mu")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,world", [(7, 2), (2, 3)])
+def test_strong_scaling_step_is_independent_of_the_partition(total, world):
+    """A ``total``-light-curve batch evaluated by ``world`` ranks (block partition, chunks of 2 with a ragged tail, one
+    all_gather) gives every rank the same vector as one process evaluating the whole batch -- also when shards are unequal
+    (7 over 2) or empty (2 over 3)."""
+    import _oracle_backend as ob
+    n = 48
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q, total, n, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    whole = make_shard(total, 0, 1, n, "cfg3")
+    ref, ref_ll = sharded_batch_step(whole, total, None, _compute=ob.mll_value_grad)       # single process: no collective
+    assert torch.equal(ref_ll, ref["mll"]) and ref_ll.shape == (total,)
+    assert [g[1] for g in got] == [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    for rank, nloc, ll, gmu in got:
+        assert torch.equal(ll, ref_ll)
+        lo, hi = shard_bounds(total, rank, world)
+        if nloc:
+            assert torch.equal(gmu, ref["g_mu"][lo:hi])
+    assert default_chunk(2048) == 64 and 1 <= default_chunk(16384) < 8
 
 
 def test_partitioning_rules():
