@@ -13,8 +13,10 @@
  *  - all work is enqueued on the caller's `stream` (a hipStream_t passed as
  *    void*; NULL = the default stream); nothing synchronises the host except the
  *    functions documented to do so;
- *  - return value: 0 ok, <0 = -(index of the first bad argument), >0 only from
- *    pgm_workspace_info (LAPACK-style 1-based index of the first non-positive pivot);
+ *  - return value: 0 ok, <0 = -(index of the first bad argument) or -99 (a launch failed).  A failed
+ *    factorisation is NOT a return value (nothing synchronises): it is reported through the device-side
+ *    `info` output of the evaluation calls, LAPACK style (0 ok, k > 0 = 1-based index of the first
+ *    non-positive pivot), with NaN in the value and in every gradient output of that problem;
  *  - no function throws or aborts; a workspace is not re-entrant (one caller
  *    thread per handle at a time).
  */

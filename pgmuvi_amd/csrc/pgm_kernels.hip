@@ -52,6 +52,23 @@ __device__ __forceinline__ void tri_decode(int idx, int& i, int& j) {
   i = idx - jj * (jj + 1) / 2;
 }
 
+// Batches: which (tile, light curve) a workgroup takes.  The dispatcher deals workgroups round-robin over the 8 XCDs in
+// launch order (x fastest, then z), each XCD with an L2 of its own: with the plain (blockIdx.x, blockIdx.z) = (tile, light
+// curve) reading, the tiles of one light curve -- which share their operand panels -- are spread over all eight L2s and every
+// panel is fetched from the memory side up to eight times (measured, 64 x N=2048: 25 % L2 hit rate in the trailing update,
+// 3.9 TB/s at the fabric).  Remapped, the workgroups that share an XCD (equal launch index mod 8) work through the light
+// curves  g, g+8, g+16, ...  one after the other, all tiles of one before the next.  A pure relabelling (bijective whenever
+// the batch is a multiple of 8, identity otherwise): placement is a speed matter only, every tile is still computed once.
+__device__ __forceinline__ void xcd_batch_remap(int& x, int& b) {
+  const int X = (int)gridDim.x, Z = (int)gridDim.z;
+  if (Z & 7) return;
+  const int L = x + X * b;
+  const int g = L & 7, s = L >> 3;
+  const int ci = s / X;
+  b = __builtin_amdgcn_readfirstlane(g + 8 * ci);
+  x = __builtin_amdgcn_readfirstlane(s - ci * X);
+}
+
 // ---------------------------------------------------------------------------
 // Per-point factors.  GPyTorch evaluates cos(2 pi (x_i mu - x_j mu)); the angle
 // difference is expanded (cos a cos b + sin a sin b) so the N^2 pass needs no
@@ -722,9 +739,10 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
   using C = CfgTrsmChain;
   __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
   if ((int)blockIdx.x >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x - nslabs); return; }
-  const int b = blockIdx.z;
-  const int slab = blockIdx.x & 3;
-  int jb = blockIdx.x >> 2;
+  int b = blockIdx.z, bx = blockIdx.x;
+  if ((int)gridDim.x == nslabs) xcd_batch_remap(bx, b);          // (no planned tiles in the grid: batches, panel sweep)
+  const int slab = bx & 3;
+  int jb = bx >> 2;
   if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
   double* A = P.A + b * P.sA;
   double* Cb = A + (int64_t)k * NB * P.ld + jb * NB + slab * C::BN;
@@ -775,14 +793,15 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
 // ---------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi) {
-  const int b = blockIdx.z;
+  int b = blockIdx.z, bx = blockIdx.x;
+  xcd_batch_remap(bx, b);
   constexpr int SUB = NB / C::BM;
   static_assert(C::BM == C::BN, "square tiles");
-  // (An XCD-aware 8x8 super-block order was measured and rejected at this size: a whole
-  //  trailing update is only 1-2 co-resident sets of tiles, so the empty tiles of the
-  //  trapezoid unbalance the XCDs more than the L2 reuse returns.)
-  const int sub = blockIdx.x % (SUB * SUB);
-  int tile = blockIdx.x / (SUB * SUB);
+  // (Single light curve: an XCD-aware 8x8 super-block order of the tiles was measured and rejected at N=4096: a whole
+  //  trailing update is only 1-2 co-resident sets of tiles, so the empty tiles of the trapezoid unbalance the XCDs more
+  //  than the L2 reuse returns -- and the matrix sits in the Infinity Cache anyway.)
+  const int sub = bx % (SUB * SUB);
+  int tile = bx / (SUB * SUB);
   const int si = sub / SUB, sj = sub % SUB;
   const int kend = k0 + dp - 1;
   const int nR = P.need_grad ? kend + 1 : 0;              // inverse-factor tiles per block row
@@ -819,7 +838,7 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 // parameter and tile (summed in fixed order by k_finalize: bitwise reproducible).
 // ---------------------------------------------------------------------------
 #ifndef PGM_BIG_PF
-#define PGM_BIG_PF 1
+#define PGM_BIG_PF 2            // two chunks in flight: 64 x N=2048 13.83 -> 13.64 ms, 8 x N=4096 12.27 -> 12.19 ms
 #endif
 using CfgBig = TileCfg<128, 128, 64, 64, PGM_BIG_PF>;
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
@@ -836,8 +855,7 @@ static_assert(EPI_SLOTS >= 3 * 2 + 2, "epilogue staging needs room for one 2-D m
 // nb * AINV_SPLITS workgroups of the k_lauum_grad launch (they are independent of it, and short).
 // ---------------------------------------------------------------------------
 constexpr int AINV_SPLITS = 32;
-__device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, double* red) {
-  const int b = blockIdx.z;
+__device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, double* red, int b) {
   const double* A = P.A + b * P.sA;
   const double* Vjj = P.Dinv + b * P.sDinv + ((int64_t)jb * 2 + 1) * NB * NB;
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -865,20 +883,21 @@ __device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, 
 __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
   __shared__ double red[NB];
   if (P.info[blockIdx.z] != 0) return;
-  ainv_diag_item(P, (int)blockIdx.x, (int)blockIdx.y, red);
+  ainv_diag_item(P, (int)blockIdx.x, (int)blockIdx.y, red, (int)blockIdx.z);
 }
 
 template <int D, int ORDER>
 __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   using C = CfgBig;
-  const int b = blockIdx.z;
+  int b = blockIdx.z, bx = blockIdx.x;
+  xcd_batch_remap(bx, b);
   if (P.info[b] != 0) return;
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   // the diag(A^-1) items ride at the end of the grid (placed first they delay the long inverse tiles: +0.04 ms)
-  if ((int)blockIdx.x >= P.nitems) { const int a = (int)blockIdx.x - P.nitems; ainv_diag_item(P, a % P.nb, a / P.nb, lds); return; }
+  if (bx >= P.nitems) { const int a = bx - P.nitems; ainv_diag_item(P, a % P.nb, a / P.nb, lds, b); return; }
   // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
   // that no single workgroup sets the makespan; the contraction below is linear in the tile
-  const int lb = (int)blockIdx.x;
+  const int lb = bx;
   const int4 item = P.items[lb];
   const int i = item.x, j = item.y, p0 = item.z, plen = item.w & 0xffff;
   double* A = P.A + b * P.sA;

@@ -629,6 +629,64 @@ def test_nuts_potential_and_short_run_vs_oracle(dev):
         assert np.allclose(a[k], b[k], rtol=1e-6, atol=1e-9), k
 
 
+def test_config5_at_its_stated_size(dev):
+    """BASELINE config 5 as stated -- 8 chains x (N=2048, Q=4), default priors (``pgmuvi/lightcurve.py:3235-3330``) -- in one
+    batched HIP evaluation per tick: potential and gradient of the first and the last chain against the oracle's autograd, then
+    a short NUTS run of all 8 chains whose chains 0 and 1 must visit the states of the same run driven by the oracle stand-in
+    (a chain's random stream depends on the seed and its id only)."""
+    import _oracle_backend as ob
+    from pgmuvi_amd import mcmc
+    C, n, Q = 8, 2048, 4
+    xs, ys, ns = [], [], []
+    for c in range(C):
+        (t, y, e), _ = syn.cfg3_lightcurve(5000 + c, n_obs=n)
+        xs.append(t.double().reshape(n, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+    x, y, nz = torch.stack(xs), torch.stack(ys), torch.stack(ns)
+    pot = mcmc.SMPotential(x.to(dev), y.to(dev), nz.to(dev), num_mixtures=Q)
+    rng = np.random.default_rng(9)
+    z = rng.normal(0, 0.3, (C, pot.P))
+    z[:, 1 + Q:1 + 2 * Q] += np.log(1.0 / np.array([150.0, 67.0, 400.0, 31.0]))
+    z[:, 1 + 2 * Q:1 + 3 * Q] += np.log(0.1 / np.array([150.0, 67.0, 400.0, 31.0]))
+    U, G = pot(z)
+    assert np.isfinite(U).all() and np.isfinite(G).all()
+    for c in (0, C - 1):
+        zt = torch.tensor(z[c], dtype=D, requires_grad=True)
+        ref = orc.nuts_potential(zt, x[c], y[c], nz[c], Q, 1, y[c].mean(), y[c].std() / 10)
+        ref.backward()
+        assert abs(U[c] - float(ref.detach())) < 1e-9 * n * max(1.0, abs(float(ref.detach())) / n)
+        assert np.allclose(G[c], zt.grad.numpy(), rtol=1e-7, atol=1e-6)
+    init = {"mean_module.mean_prior": np.array(0.0), "covar_module.mixture_weights_prior": np.array([0.5, 0.12, 0.05, 0.02]),
+            "covar_module.mixture_means_prior": (1.0 / np.array([150.0, 67.0, 400.0, 31.0])).reshape(Q, 1, 1),
+            "covar_module.mixture_scales_prior": (0.1 / np.array([150.0, 67.0, 400.0, 31.0])).reshape(Q, 1, 1)}
+    kw = dict(num_mixtures=Q, num_samples=2, warmup_steps=1, seed=11, group_by_chain=True, max_tree_depth=1, initial_values=init)
+    a = mcmc.run_mcmc(x.to(dev), y.to(dev), nz.to(dev), **kw)
+    b = mcmc.run_mcmc(x[:2], y[:2], nz[:2], compute=ob.mll_value_grad, **kw)
+    assert a["covar_module.mixture_means_prior"].shape[0] == C
+    assert np.array_equal(a["_diagnostics"]["n_leapfrog"][:2], b["_diagnostics"]["n_leapfrog"])
+    for k in ("covar_module.mixture_means_prior", "covar_module.mixture_weights_prior", "covar_module.mixture_scales_prior", "mean_module.mean_prior"):
+        assert np.allclose(a[k][:2], b[k], rtol=1e-6, atol=1e-9), k
+
+
+def test_config3_per_gpu_shard_of_64(dev):
+    """BASELINE config 3's per-GPU shard at 8 GPUs -- 64 light curves x N=2048, Q=4 -- through the code path of
+    ``bench.py --total-batch`` (``make_shard`` + ``sharded_batch_step``): first and last against the oracle, every value finite,
+    and the same numbers whether the shard goes in one launch set or in chunks of 24 with a ragged tail."""
+    from pgmuvi_amd.batch import make_shard, sharded_batch_step
+    B, n = 64, 2048
+    shard = make_shard(B, 0, 1, n, "cfg3", dev)
+    out, ll = sharded_batch_step(shard, B, 64)
+    out24, ll24 = sharded_batch_step(shard, B, 24)
+    torch.cuda.synchronize()
+    assert ll.shape == (B,) and int(out["info"].abs().max()) == 0 and bool(torch.isfinite(ll).all())
+    assert torch.allclose(ll, ll24, rtol=0, atol=1e-12) and torch.allclose(out["g_mu"], out24["g_mu"], rtol=1e-10, atol=1e-14)
+    cpu = {k: v.cpu() for k, v in shard.items()}
+    for i in (0, B - 1):
+        val, gr = orc.mll_value_grad_closed_form(cpu["x"][i], cpu["y"][i], cpu["mean"][i], cpu["noise"][i], cpu["w"][i], cpu["mu"][i], cpu["v"][i])
+        assert abs(float(val) - float(ll[i])) < MLL_TOL
+        for p_ in ("w", "mu", "v"):
+            assert _rel(out[f"g_{p_}"][i].reshape(-1), gr[p_].reshape(-1)) < GRAD_RTOL
+
+
 def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
     """the periodogram kernel behind the astropy-shaped ``LombScargle`` against the numpy
     oracle -- the notebook's 89-point light curve (whose two highest peaks are the initial frequencies the reference
@@ -1156,6 +1214,19 @@ def test_multiband_lomb_scargle_vs_oracle(dev):
         p = mb.power(f, method="fast")
         assert np.allclose(p, lso.multiband_fast(t, y, bands, dy, f), rtol=1e-9, atol=1e-12)
         assert 0.0 < p.max() <= 1.0
+
+
+def test_c_abi_from_a_c_caller(dev):
+    """The ABI exercised from C, not only through ctypes: ``tools/selftest`` (built by ``__graft_entry__.build()``; plain C++ host
+    code linking ``libpgmuvi_hip.so``, no torch, no oracle) checks every entry point against a naive CPU implementation of its
+    own -- dense kernel, 1-D / 2-D, ragged sizes, batched == single, non-PD reporting -- and exits non-zero on any mismatch."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "selftest")
+    if not os.path.exists(exe):
+        pytest.skip("tools/selftest not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = subprocess.run([exe, "1024"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "FAIL" not in r.stdout and r.stdout.count("OK") >= 10
 
 
 def test_performance_guards(dev):
