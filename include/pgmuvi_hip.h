@@ -188,6 +188,20 @@ int pgm_lomb_scargle_f64(const double* t, const double* y, const double* dy, int
                          const double* freq, int64_t nf, int fit_mean, double* scratch, double* power,
                          void* stream);
 
+/*
+ * The same periodogram by the FFT approximation astropy's default `method='auto'` takes on a regular grid of more than
+ * 200 frequencies -- i.e. what `LS.power(freq, assume_regular_frequency=True)` at pgmuvi/lightcurve.py:4514 (and the
+ * per-band periodograms behind `LombScargleMultiband.power(method='fast')`, pgmuvi/multiband_ls_significance.py:202)
+ * actually returns: the trigonometric sums on f_k = f0 + k df, k < nf, come from inverse FFTs of the samples spread onto
+ * a regular grid of 2^ceil(log2(oversampling nf)) points with 4-point Lagrange weights (Press & Rybicki 1989; astropy's
+ * defaults: oversampling 5).  It differs from the exact sums by up to 1e-2 in the power at the high-frequency end.
+ * scratch: [batch][pgm_lomb_scargle_fast_scratch_doubles(n, nf, oversampling)] doubles of caller-owned device memory.
+ */
+int64_t pgm_lomb_scargle_fast_scratch_doubles(int64_t n, int64_t nf, int oversampling);
+int pgm_lomb_scargle_fast_f64(const double* t, const double* y, const double* dy, int64_t n, int batch,
+                              double f0, double df, int64_t nf, int fit_mean, int oversampling,
+                              double* scratch, double* power, void* stream);
+
 /* fp64 MFMA issue-rate probe (TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on
  * every CU); used once by bench.py to report the measured peak beside the
  * datasheet figure.  Synchronises. */

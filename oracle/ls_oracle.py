@@ -159,7 +159,7 @@ def power_auto(t, y, dy, freq, fit_mean=True, center_data=True):
     return power(t, y, dy, freq, fit_mean, center_data)
 
 
-def multiband_fast(t, y, bands, dy, freq, fit_mean=True, center_data=True):
+def multiband_fast(t, y, bands, dy, freq, fit_mean=True, center_data=True, sb_auto=False):
     """Multiband periodogram, "fast" form (VanderPlas & Ivezic 2015; what ``pgmuvi/multiband_ls_significance.py:51-106`` asks
     astropy for): per-band standard-normalised powers weighted by each band's reference chi^2 about its weighted mean."""
     t = np.asarray(t, dtype=float); y = np.asarray(y, dtype=float); bands = np.asarray(bands)
@@ -169,7 +169,7 @@ def multiband_fast(t, y, bands, dy, freq, fit_mean=True, center_data=True):
         dyb = None if dy is None else np.asarray(dy, dtype=float)[m]
         w = np.ones(int(m.sum())) if dyb is None else dyb ** -2.0
         chi2_0.append(np.sum(w * (y[m] - np.dot(w, y[m]) / w.sum()) ** 2))
-        powers.append(power(t[m], y[m], dyb, freq, fit_mean, center_data))
+        powers.append((power_auto if sb_auto else power)(t[m], y[m], dyb, freq, fit_mean, center_data))
     chi2_0 = np.asarray(chi2_0)
     return np.dot(chi2_0 / chi2_0.sum(), np.asarray(powers))
 

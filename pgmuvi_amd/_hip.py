@@ -52,6 +52,9 @@ SYMBOLS = {
     "pgm_fit_destroy": (c_int, [c_void_p]),
     "pgm_lomb_scargle_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p]),
+    "pgm_lomb_scargle_fast_scratch_doubles": (c_int64, [c_int64, c_int64, c_int]),
+    "pgm_lomb_scargle_fast_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int64, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p]),
 }
 
 
@@ -332,6 +335,31 @@ def lomb_scargle(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], f
         rc = load().pgm_lomb_scargle_f64(_ptr(td), _ptr(yd), _ptr(dd), n, B, _ptr(fd), nf, 1 if fit_mean else 0, _ptr(scratch),
                                          _ptr(power), current_stream_ptr(dev))
     _check(rc, "pgm_lomb_scargle_f64")
+    return power
+
+
+def lomb_scargle_fast(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], f0: float, df: float, nf: int, fit_mean=True,
+                      center_data=True, oversampling: int = 5) -> torch.Tensor:
+    """The periodogram on the regular grid f0 + df * arange(nf) by the FFT approximation of astropy's ``method='auto'``
+    (pgm_lomb_scargle_fast_f64): (B, nf) for B light curves (B, N)."""
+    require_gpu(y, "lomb_scargle_fast")
+    if not (fit_mean or center_data):
+        raise NotImplementedError("fit_mean=False with center_data=False (an uncentred classical periodogram) is not implemented")
+    dev = y.device
+    if y.dim() == 1:
+        t, y = t.reshape(1, -1), y.reshape(1, -1)
+        dy = None if dy is None else dy.reshape(1, -1)
+    B, n = y.shape
+    td = _dev64(t.expand(B, n), dev)
+    yd = _dev64(y, dev)
+    dd = None if dy is None else _dev64(dy.expand(B, n), dev)
+    per = int(load().pgm_lomb_scargle_fast_scratch_doubles(n, int(nf), int(oversampling)))
+    scratch = torch.empty((B, per), dtype=torch.float64, device=dev)
+    power = torch.empty((B, int(nf)), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().pgm_lomb_scargle_fast_f64(_ptr(td), _ptr(yd), _ptr(dd), n, B, float(f0), float(df), int(nf), 1 if fit_mean else 0,
+                                              int(oversampling), _ptr(scratch), _ptr(power), current_stream_ptr(dev))
+    _check(rc, "pgm_lomb_scargle_fast_f64")
     return power
 
 

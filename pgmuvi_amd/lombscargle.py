@@ -14,10 +14,13 @@ periodogram sums, one thread per frequency, batched over light curves) and, for 
 ``astropy.timeseries`` so that the reference's own ``fit_LS`` runs unmodified where astropy is absent.
 There is no CPU path: the periodogram runs on the GPU or raises.
 
-The periodogram is the published generalised Lomb-Scargle (Zechmeister & Kuerster 2009); astropy's default
-``method='auto'`` approximates the same sums with an FFT (relative differences ~1e-3 in the power, none in
-the peak positions on the 5-samples-per-peak grid).  The false-alarm formulas (Baluev 2008) are restated
-from astropy's published implementation -- unverified against an installed astropy.
+The periodogram is the published generalised Lomb-Scargle (Zechmeister & Kuerster 2009).  ``power(method=...)`` follows
+astropy's rule: ``'auto'`` (the default, what pgmuvi calls) takes the FFT approximation of Press & Rybicki on a regular
+grid of more than 200 frequencies -- ``pgm_lomb_scargle_fast_f64``: samples spread onto an oversampled grid, inverse FFTs,
+the tau form -- and the exact sums otherwise; ``'fast'`` / ``'slow'`` force one or the other.  The approximation is what
+the reference's recorded outputs contain: it differs from the exact sums by up to 1e-2 in the power at the high-frequency
+end and reorders near-equal peaks (``oracle/ls_oracle.py``).  The false-alarm formulas (Baluev 2008) are restated from
+astropy's published implementation -- unverified against an installed astropy.
 """
 from __future__ import annotations
 
@@ -47,10 +50,31 @@ def _compute_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _regular_grid(f: np.ndarray):
+    """(f0, df) when ``f`` is a regular increasing grid (astropy's ``_is_regular``), else None."""
+    if f.ndim != 1 or f.size < 2:
+        return None
+    d = np.diff(f)
+    if not (d[0] > 0 and np.allclose(d, d[0])):
+        return None
+    return float(f[0]), float(d[0])
+
+
 def periodogram_batched(t: torch.Tensor, y: torch.Tensor, dy: Optional[torch.Tensor], freq: torch.Tensor,
-                        fit_mean=True, center_data=True) -> torch.Tensor:
+                        fit_mean=True, center_data=True, method="slow", assume_regular_frequency=False) -> torch.Tensor:
     """Standard-normalised floating-mean Lomb-Scargle power, (B, Nf), for B light curves (B, N) on the GPU and
-    one frequency grid (Nf,) shared by the batch."""
+    one frequency grid (Nf,) shared by the batch.  ``method``: 'slow' exact sums (default here), 'fast' the FFT
+    approximation (regular grid), 'auto' astropy's choice between the two."""
+    if method not in ("auto", "fast", "slow", "cython", "scipy"):
+        raise NotImplementedError(f"Lomb-Scargle method {method!r} is not implemented (auto, fast, slow)")
+    if method in ("auto", "fast"):
+        f = freq.detach().cpu().numpy().astype(np.float64).reshape(-1)
+        if method == "fast" or f.size > 200:
+            reg = (float(f[0]), float(f[1] - f[0])) if (assume_regular_frequency and f.size > 1) else _regular_grid(f)
+            if reg is not None and reg[0] >= 0.0:
+                return _hip.lomb_scargle_fast(t, y, dy, reg[0], reg[1], f.size, fit_mean, center_data)
+            if method == "fast":
+                raise ValueError("method='fast' needs a regular frequency grid with f0 >= 0")
     return _hip.lomb_scargle(t, y, dy, freq, fit_mean, center_data)
 
 
@@ -94,7 +118,7 @@ class LombScargle:
         dd = None if self.dy is None else torch.as_tensor(self.dy, dtype=D, device=dev).reshape(1, -1)
         ff = torch.as_tensor(f.reshape(-1), dtype=D, device=dev)
         p = periodogram_batched(tt, yy, dd, ff, self.fit_mean if fit_mean is None else fit_mean,
-                                self.center_data if center_data is None else center_data)
+                                self.center_data if center_data is None else center_data, method, assume_regular_frequency)
         return p[0].cpu().numpy().reshape(shape)
 
     # ---- false-alarm probabilities ('standard' normalisation; Baluev 2008 as implemented by astropy)
@@ -166,7 +190,7 @@ class LombScargleMultiband:
             w = np.ones(int(m.sum())) if dyb is None else dyb ** -2.0
             yb = self.y[m]
             chi2_0.append(float(np.sum(w * (yb - np.dot(w, yb) / w.sum()) ** 2)))
-            powers.append(LombScargle(self.t[m], yb, dyb, fit_mean=self.fit_mean, center_data=self.center_data).power(f.reshape(-1)))
+            powers.append(LombScargle(self.t[m], yb, dyb, fit_mean=self.fit_mean, center_data=self.center_data).power(f.reshape(-1), method=sb_method))
         chi2_0 = np.asarray(chi2_0)
         return np.dot(chi2_0 / chi2_0.sum(), np.asarray(powers)).reshape(f.shape)
 

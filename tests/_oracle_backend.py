@@ -90,15 +90,26 @@ def lomb_scargle(t, y, dy, freq, fit_mean=True, center_data=True):
     return torch.as_tensor(out, dtype=torch.float64, device=y.device)
 
 
-def lomb_scargle_auto(t, y, dy, freq, fit_mean=True, center_data=True):
-    """TEST-ONLY stand-in with astropy's ``method='auto'`` rule (FFT approximation on long regular grids)."""
+def lomb_scargle_fast(t, y, dy, f0, df, nf, fit_mean=True, center_data=True, oversampling=5):
+    """TEST-ONLY stand-in for ``pgmuvi_amd._hip.lomb_scargle_fast`` (the FFT approximation, by the numpy oracle)."""
     import numpy as np
     from oracle import ls_oracle
-    f = freq.detach().cpu().numpy()
-    out = np.stack([ls_oracle.power_auto(t[b].detach().cpu().numpy(), y[b].detach().cpu().numpy(),
-                                         None if dy is None else dy[b].detach().cpu().numpy(), f, fit_mean, center_data)
+    if y.dim() == 1:
+        t, y = t.reshape(1, -1), y.reshape(1, -1)
+        dy = None if dy is None else dy.reshape(1, -1)
+    t = t.expand(y.shape)
+    out = np.stack([ls_oracle.power_fast(t[b].detach().cpu().numpy(), y[b].detach().cpu().numpy(),
+                                         None if dy is None else dy[b].detach().cpu().numpy(), f0, df, nf, fit_mean, center_data)
                     for b in range(y.shape[0])])
     return torch.as_tensor(out, dtype=torch.float64, device=y.device)
+
+
+def lomb_scargle_fast_by_exact_sums(t, y, dy, f0, df, nf, fit_mean=True, center_data=True, oversampling=5):
+    """TEST-ONLY: the same entry point answered with the exact sums (to show what the approximation changes)."""
+    import numpy as np
+    return lomb_scargle(t.reshape(1, -1) if y.dim() == 1 else t.expand(y.shape), y.reshape(1, -1) if y.dim() == 1 else y,
+                        None if dy is None else (dy.reshape(1, -1) if y.dim() == 1 else dy),
+                        torch.as_tensor(f0 + df * np.arange(nf), dtype=torch.float64), fit_mean, center_data)
 
 
 def mll_dense(A, r, jitter=0.0, need_grad=True, workspace=None):

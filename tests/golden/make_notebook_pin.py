@@ -117,7 +117,9 @@ def run_fit_ls_seeded(lc, backend, ls_backend, max_iter=1000):
     own ``fit_LS`` through the astropy-shaped shim (``pgmuvi_amd.lombscargle.install_as_astropy``)."""
     import torch
     from pgmuvi_amd import _hip, lombscargle
+    import _oracle_backend as ob
     with mock.patch.object(_hip, "mll_value_grad", backend), mock.patch.object(_hip, "lomb_scargle", ls_backend), \
+            mock.patch.object(_hip, "lomb_scargle_fast", ob.lomb_scargle_fast), \
             mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
         return lc.fit(model="1D", num_mixtures=2, training_iter=max_iter, miniter=50, lr=0.05)
 

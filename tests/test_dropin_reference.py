@@ -189,7 +189,7 @@ def test_reference_default_fit_seeds_from_lomb_scargle_like_the_notebook():
         import make_notebook_pin as nb
         torch.manual_seed(0)
         lc = nb.build_lightcurve()
-        with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+        with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(_hip, "lomb_scargle_fast", ob.lomb_scargle_fast), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
             f, sig = lc.fit_LS(num_peaks=10)
         assert bool(sig[0]) and bool(sig[1])
         assert [round(float(v), 4) for v in f[:2]] == nb.NOTEBOOK["nb_init_means"], f[:4]
@@ -221,8 +221,9 @@ def test_reference_fit_LS_reproduces_the_lomb_scargle_notebooks_recorded_peaks()
         lc1d = lc2d.select_bands(["band 0"])
         assert len(lc1d.xdata) == rec["nb1d_n_points"]
         got = {}
-        for name, ls in (("exact", ob.lomb_scargle), ("auto", ob.lomb_scargle_auto)):
-            with mock.patch.object(_hip, "lomb_scargle", ls), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+        for name, ls in (("exact", ob.lomb_scargle_fast_by_exact_sums), ("auto", ob.lomb_scargle_fast)):
+            with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(_hip, "lomb_scargle_fast", ls), \
+                    mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
                 f, sig, grid, power = lc1d.fit_LS(freq_only=False, num_peaks=5, return_full=True)
                 fb, pb = lc2d.fit_LS(freq_only=True, use_best_band_init=True)
                 fd, pd_ = lc2d.fit_LS(freq_only=True)
@@ -243,7 +244,7 @@ def test_reference_fit_LS_reproduces_the_lomb_scargle_notebooks_recorded_peaks()
         # two-period light curve + dense band (cell 34): band counts, the strongest peak and the 66-day peak are the recorded ones
         lc4 = nb.build_two_periods_with_dense_band()
         assert [int(np.sum(lc4.band == b)) for b in np.unique(lc4.band)] == rec["nbmb2_band_counts"]
-        with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle_auto), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
+        with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(_hip, "lomb_scargle_fast", ob.lomb_scargle_fast), mock.patch.object(lombscargle, "_compute_device", lambda: torch.device("cpu")):
             f8, s8 = lc4.fit_LS(freq_only=False, num_peaks=8, return_full=False)
         f8 = [round(float(v), 6) for v in f8]
         assert f8[0] == rec["nbmb2_peak_freqs"][0] and bool(s8[0]) and rec["nbmb2_peak_freqs"][7] in f8, f8

@@ -697,9 +697,10 @@ def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
     t, y, dy = p["x"], p["y"], np.sqrt(p["noise"])
     ls = L.LombScargle(t, y, dy)
     f = ls.autofrequency(nyquist_factor=5)
-    pw = ls.power(f, assume_regular_frequency=True)
-    ref = lso.power(t, y, dy, f)
-    assert np.allclose(pw, ref, rtol=1e-9, atol=1e-12)
+    pw = ls.power(f, assume_regular_frequency=True)             # what pgmuvi calls: astropy's 'auto' = the FFT approximation here
+    assert f.size > 200 and np.allclose(pw, lso.power_fast(t, y, dy, f[0], f[1] - f[0], f.size), rtol=1e-9, atol=1e-11)
+    assert np.allclose(ls.power(f, method="slow"), lso.power(t, y, dy, f), rtol=1e-9, atol=1e-12)
+    assert np.allclose(ls.power(f[:150]), lso.power(t, y, dy, f[:150]), rtol=1e-9, atol=1e-12)   # short grid: exact sums
     from scipy.signal import find_peaks
     pk, _ = find_peaks(pw, distance=5)
     pk = pk[np.argsort(pw[pk])][::-1]
@@ -713,6 +714,9 @@ def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
         out = L.periodogram_batched(tt.to(dev).reshape(1, -1), yy.to(dev).reshape(1, -1), None if dyv is None else dyv.to(dev).reshape(1, -1), sub.to(dev))
         ref = lso.power(tt.numpy(), yy.numpy(), None if dyv is None else dyv.numpy(), sub.numpy())
         assert np.allclose(out[0].cpu().numpy(), ref, rtol=1e-8, atol=1e-12)
+    fast = L.periodogram_batched(tt.to(dev).reshape(1, -1), yy.to(dev).reshape(1, -1), ee.to(dev).reshape(1, -1), grid.to(dev), method="auto")
+    gnp = grid.numpy()
+    assert np.allclose(fast[0].cpu().numpy(), lso.power_fast(tt.numpy(), yy.numpy(), ee.numpy(), gnp[0], gnp[1] - gnp[0], gnp.size), rtol=1e-8, atol=1e-10)
     full = L.periodogram_batched(tt.to(dev).reshape(1, -1), yy.to(dev).reshape(1, -1), ee.to(dev).reshape(1, -1), grid.to(dev))
     assert full.shape == (1, grid.numel()) and abs(float(grid[int(full[0].argmax())]) - 1 / 150.0) < 2 * float(grid[1] - grid[0])
     # batch of different light curves on one grid == singles
@@ -732,10 +736,10 @@ def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
 
 def test_lomb_scargle_notebook_recorded_peaks(dev, golden_dir):
     """The HIP periodogram on the light curves of the reference's Lomb-Scargle notebook (tests/golden/make_ls_notebook_pin.py):
-    equal to the oracle's exact sums, and the five strongest peaks of band 0 are the five frequencies the notebook recorded
-    (``fit_LS``'s peak rule: ``find_peaks(power, distance=5)`` by decreasing power), the first three in the recorded order
-    (the recorded order of the 4th and 5th, whose exact powers differ by 4e-4, is that of astropy's FFT approximation --
-    ``oracle/ls_oracle.power_fast``); the best-band periodogram of the three-band curve peaks at the recorded period/height."""
+    equal to the oracle's restatement of astropy's FFT approximation (what ``method='auto'`` resolves to on this grid), and
+    the five strongest peaks of band 0 are the five frequencies the notebook recorded, in the recorded order (``fit_LS``'s
+    peak rule: ``find_peaks(power, distance=5)`` by decreasing power; with the exact sums the 4th and 5th, whose powers
+    differ by 4e-4, swap); the best-band periodogram of the three-band curve peaks at the recorded period/height."""
     from scipy.signal import find_peaks
     from pgmuvi_amd import lombscargle as L
     from oracle import ls_oracle as lso
@@ -746,14 +750,15 @@ def test_lomb_scargle_notebook_recorded_peaks(dev, golden_dir):
     ls = L.LombScargle(t[m], y[m], dy[m])
     f = ls.autofrequency(nyquist_factor=5)
     assert len(f) == int(p["nb1d_grid_length"])
-    pw = ls.power(f, assume_regular_frequency=True)
-    assert np.allclose(pw, lso.power(t[m], y[m], dy[m], f), rtol=1e-9, atol=1e-12)
+    pw = ls.power(f, assume_regular_frequency=True)             # the call of fit_LS: astropy's 'auto' rule -> the FFT approximation
+    assert np.allclose(pw, lso.power_fast(t[m], y[m], dy[m], f[0], f[1] - f[0], f.size), rtol=1e-9, atol=1e-11)
+    assert np.allclose(ls.power(f, method="slow"), lso.power(t[m], y[m], dy[m], f), rtol=1e-9, atol=1e-12)
     pk_all, _ = find_peaks(pw, distance=5)
     pk_all = pk_all[np.argsort(pw[pk_all])][::-1]
     pk = pk_all[:5]
     got = [round(float(v), 6) for v in f[pk]]
     rec = [round(float(v), 6) for v in p["nb1d_peak_freqs"]]
-    assert sorted(got) == sorted(rec) and got[:3] == rec[:3], got
+    assert got == rec, got                                      # all five, in the recorded order
     assert abs(1.0 / f[pk[0]] - float(p["nbmb_best_band"][0])) < 1e-5 and abs(pw[pk[0]] - float(p["nbmb_best_band"][1])) < 2e-6
     # (the recorded significance flags come from the reference's own phase-scramble bootstrap over this periodogram -- a band
     #  selected from a 2-D light curve keeps the multiband code path -- and are covered by tests/test_dropin_reference.py)
@@ -761,7 +766,8 @@ def test_lomb_scargle_notebook_recorded_peaks(dev, golden_dir):
     # the multiband periodogram (per-band HIP periodograms, chi^2-weighted) equals the oracle's restatement of it
     mb = L.LombScargleMultiband(t, y, wl, dy)
     fm = mb.autofrequency(nyquist_factor=5)
-    assert np.allclose(mb.power(fm, method="fast"), lso.multiband_fast(t, y, wl, dy, fm), rtol=1e-9, atol=1e-12)
+    assert np.allclose(mb.power(fm, method="fast"), lso.multiband_fast(t, y, wl, dy, fm, sb_auto=True), rtol=1e-9, atol=1e-11)
+    assert np.allclose(mb.power(fm, method="fast", sb_method="slow"), lso.multiband_fast(t, y, wl, dy, fm), rtol=1e-9, atol=1e-12)
 
 
 def test_dense_backend_vs_oracle(dev):
@@ -1211,9 +1217,11 @@ def test_multiband_lomb_scargle_vs_oracle(dev):
     for dy in (e, None):
         mb = L.LombScargleMultiband(t, y, bands, dy=dy)
         f = mb.autofrequency(nyquist_factor=3)
-        p = mb.power(f, method="fast")
+        p = mb.power(f, method="fast", sb_method="slow")
         assert np.allclose(p, lso.multiband_fast(t, y, bands, dy, f), rtol=1e-9, atol=1e-12)
         assert 0.0 < p.max() <= 1.0
+        pa = mb.power(f, method="fast")
+        assert np.allclose(pa, lso.multiband_fast(t, y, bands, dy, f, sb_auto=True), rtol=1e-9, atol=1e-11)
 
 
 def test_c_abi_from_a_c_caller(dev):

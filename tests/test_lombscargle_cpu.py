@@ -48,13 +48,23 @@ def test_pure_sinusoid_and_grid():
 
 def test_class_surface_matches_oracle_and_astropy_conventions():
     t, y, e = _data(150)
-    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(L, "_compute_device", lambda: torch.device("cpu")):
+    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(_hip, "lomb_scargle_fast", ob.lomb_scargle_fast), mock.patch.object(L, "_compute_device", lambda: torch.device("cpu")):
         ls = L.LombScargle(torch.as_tensor(t), torch.as_tensor(y), torch.as_tensor(e))
         f = ls.autofrequency(nyquist_factor=5)
         assert np.allclose(f, lso.autofrequency(t))
-        p = ls.power(f, assume_regular_frequency=True)
-        assert isinstance(p, np.ndarray) and p.shape == f.shape
-        assert np.allclose(p, lso.power(t, y, e, f), rtol=0, atol=1e-13)
+        p = ls.power(f, assume_regular_frequency=True)                  # astropy's 'auto': the FFT approximation on this grid
+        assert isinstance(p, np.ndarray) and p.shape == f.shape and f.size > 200
+        assert np.allclose(p, lso.power_fast(t, y, e, f[0], f[1] - f[0], f.size), rtol=0, atol=1e-13)
+        assert np.array_equal(p, ls.power(f)) and np.array_equal(p, ls.power(f, method="fast"))
+        ps = ls.power(f, method="slow")
+        assert np.allclose(ps, lso.power(t, y, e, f), rtol=0, atol=1e-13)
+        assert 1e-6 < np.abs(ps - p).max() < 0.05 and np.abs(ps - p)[:100].max() < 1e-3      # an approximation, best at low frequencies
+        assert np.allclose(ls.power(f[:150]), lso.power(t, y, e, f[:150]), rtol=0, atol=1e-13)   # short grid: exact sums
+        irregular = np.sort(np.concatenate([f[:300], f[300:] * 1.0003]))
+        assert np.allclose(ls.power(irregular), lso.power(t, y, e, irregular), rtol=0, atol=1e-13)
+        with pytest.raises(ValueError):
+            ls.power(irregular, method="fast")
+        p = ps
         fap_max = ls.false_alarm_probability(p.max(), method="davies")
         fap_single = ls.false_alarm_probability(p, method="single")
         assert np.allclose(fap_single, lso.fap_single(p, t.size))
@@ -77,7 +87,7 @@ def test_batched_seeding_finds_the_injected_periods():
         (t, y, e), p = syn.cfg3_lightcurve(i, n_obs=256)
         ts.append(t.double()); ys.append(y.double()); es.append(e.double()); per.append(p)
     T, Y, E = torch.stack(ts), torch.stack(ys), torch.stack(es)
-    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle):
+    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(_hip, "lomb_scargle_fast", ob.lomb_scargle_fast):
         freqs, pows, grid = L.seed_frequencies(T, Y, E, num_peaks=2)
     assert freqs.shape == (3, 2) and grid.ndim == 1
     for b in range(3):        # the leading period (amplitude 1) is the highest peak, to within one grid step
@@ -97,13 +107,16 @@ def test_multiband_fast_periodogram_vs_oracle():
         ts.append(t); bs.append(np.full(nb, b)); es.append(e)
         ys.append(2.0 * b + amp * np.sin(2 * np.pi * t / period + 0.3 * b) + e * rng.standard_normal(nb))
     t, y, bands, e = map(np.concatenate, (ts, ys, bs, es))
-    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(L, "_compute_device", lambda: torch.device("cpu")):
+    with mock.patch.object(_hip, "lomb_scargle", ob.lomb_scargle), mock.patch.object(_hip, "lomb_scargle_fast", ob.lomb_scargle_fast), mock.patch.object(L, "_compute_device", lambda: torch.device("cpu")):
         for dy in (e, None):
             mb = L.LombScargleMultiband(t, y, bands, dy=dy)
             f = mb.autofrequency(nyquist_factor=2)
             assert np.array_equal(f, lso.autofrequency(t, nyquist_factor=2))
-            p = mb.power(f, method="fast")
+            p = mb.power(f, method="fast", sb_method="slow")
             assert p.shape == f.shape and np.allclose(p, lso.multiband_fast(t, y, bands, dy, f), rtol=0, atol=1e-13)
+            pa = mb.power(f, method="fast")                            # per-band periodograms by astropy's 'auto' rule
+            assert np.allclose(pa, lso.multiband_fast(t, y, bands, dy, f, sb_auto=True), rtol=0, atol=1e-13)
+            p = pa
             assert abs(1.0 / f[np.argmax(p)] - period) < 0.5
             f2, p2 = mb.autopower(method="fast", nyquist_factor=2)
             assert np.array_equal(f2, f) and np.array_equal(p2, p)
