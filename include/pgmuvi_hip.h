@@ -189,6 +189,28 @@ int pgm_lomb_scargle_f64(const double* t, const double* y, const double* dy, int
                          void* stream);
 
 /*
+ * The reference's other exact-GP models (pgmuvi/gps.py:915-1342: QuasiPeriodicGPModel, MaternGPModel,
+ * PeriodicPlusStochasticGPModel, SeparableGPModel, ...) compose GPyTorch's stationary kernels with ScaleKernel /
+ * ProductKernel / AdditiveKernel; `covar_module(x)` + `mll(output, y)` + `loss.backward()` (pgmuvi/trainers.py:179-181) of
+ * such a model is this call.  The kernel is a sum of products of leaf kernels with scale factors,
+ *     K = sum_t (prod of theta[tscale[t][..]]) * prod_{l in tmask[t]} k_l(x, x'; theta[par[l]..]),
+ * leaves (parameters in theta order, constrained values): 1 RBF [l], 2-4 Matern 1/2, 3/2, 5/2 [l], 5 periodic [p, lambda],
+ * 6 rational quadratic [l, alpha], 7 cosine [p], 8 linear [v], 9 constant [c]; `dims[l]` is the bit mask of the input
+ * dimensions leaf l sees (its active_dims).  theta: [batch][nparam] device values; g_theta: d mll / d theta, same shape.
+ * Everything else (noise, mean, jitter, mll, info, workspace) as in pgm_mll_value_grad_batched_f64.  The workspace must
+ * have been created with max_q >= nparam.
+ */
+typedef struct pgm_kernel_program {
+  int nleaf, nterm, nparam;
+  unsigned char kind[6], dims[6], par[6];
+  unsigned char tmask[4], tnscale[4], tscale[4][3];
+} pgm_kernel_program;
+int pgm_mll_kernel_value_grad_f64(pgm_ws* ws, int batch, const double* x, const double* y, const double* mean,
+                                  const double* noise, const double* noise_scalar, int64_t n, int d,
+                                  const pgm_kernel_program* prog /* host */, const double* theta, double jitter, int need_grad,
+                                  double* mll, double* g_theta, double* g_noise, double* g_mean, int* info, void* stream);
+
+/*
  * The same periodogram by the FFT approximation astropy's default `method='auto'` takes on a regular grid of more than
  * 200 frequencies -- i.e. what `LS.power(freq, assume_regular_frequency=True)` at pgmuvi/lightcurve.py:4514 (and the
  * per-band periodograms behind `LombScargleMultiband.power(method='fast')`, pgmuvi/multiband_ls_significance.py:202)

@@ -306,6 +306,50 @@ def rq(x1, x2, lengthscale, alpha):
     return (1 + _sqd(_as_2d(x1) / lengthscale, _as_2d(x2) / lengthscale) / (2 * alpha)) ** (-alpha)
 
 
+def cosine(x1, x2, period):
+    r = (_sqd(_as_2d(x1), _as_2d(x2)) + 1e-30).sqrt()
+    return torch.cos(math.pi * r / period)
+
+
+def kernel_program_matrix(leaves, terms, theta, x):
+    """K(x, x) of a composed stationary kernel given as the sum-of-products program the HIP library takes
+    (``pgm_kernel_program`` of include/pgmuvi_hip.h): ``leaves`` [(kind, dims mask, first parameter)], ``terms``
+    [(leaf indices, scale-parameter indices)], ``theta`` the parameter vector.  Each leaf by the formulas above on the
+    columns its mask selects; plain torch, differentiable in ``theta``."""
+    x = _as_2d(x)
+    vals = []
+    for kind, mask, par in leaves:
+        cols = [c for c in range(x.shape[-1]) if (mask >> c) & 1]
+        xs = x[:, cols] if cols else x[:, :0]
+        t0 = theta[par]
+        if kind == 1:
+            k = rbf(xs, xs, t0)
+        elif kind in (2, 3, 4):
+            k = matern(xs, xs, t0, {2: 0.5, 3: 1.5, 4: 2.5}[kind])
+        elif kind == 5:
+            k = periodic(xs, xs, t0, theta[par + 1])
+        elif kind == 6:
+            k = rq(xs, xs, t0, theta[par + 1])
+        elif kind == 7:
+            k = cosine(xs, xs, t0)
+        elif kind == 8:
+            k = t0 * (xs @ xs.T)
+        elif kind == 9:
+            k = t0 * torch.ones(x.shape[0], x.shape[0], dtype=x.dtype)
+        else:
+            raise ValueError(kind)
+        vals.append(k)
+    K = None
+    for lv, sc in terms:
+        T = None
+        for l in lv:
+            T = vals[l] if T is None else T * vals[l]
+        for p in sc:
+            T = T * theta[p]
+        K = T if K is None else K + T
+    return K
+
+
 def mll_dense(K, y, mean, noise, jitter=0.0):
     """Per-datum MLL for an arbitrary kernel matrix K (dense back-end of the HIP library)."""
     n = y.shape[0]

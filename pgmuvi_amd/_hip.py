@@ -52,6 +52,8 @@ SYMBOLS = {
     "pgm_fit_destroy": (c_int, [c_void_p]),
     "pgm_lomb_scargle_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p]),
+    "pgm_mll_kernel_value_grad_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                              c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pgm_lomb_scargle_fast_scratch_doubles": (c_int64, [c_int64, c_int64, c_int]),
     "pgm_lomb_scargle_fast_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int64, c_int, c_int,
                                           c_void_p, c_void_p, c_void_p]),
@@ -286,6 +288,64 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
         for k in ("mll", "info", "g_w", "g_mu", "g_v", "g_noise", "g_mean"):
             if k in out:
                 out[k] = out[k][0]
+    out["workspace"] = ws
+    return out
+
+
+class _KernelProgramStruct(ctypes.Structure):
+    """``pgm_kernel_program`` of include/pgmuvi_hip.h."""
+    _fields_ = [("nleaf", c_int), ("nterm", c_int), ("nparam", c_int),
+                ("kind", ctypes.c_ubyte * 6), ("dims", ctypes.c_ubyte * 6), ("par", ctypes.c_ubyte * 6),
+                ("tmask", ctypes.c_ubyte * 4), ("tnscale", ctypes.c_ubyte * 4), ("tscale", (ctypes.c_ubyte * 3) * 4)]
+
+
+def kernel_program_struct(program) -> _KernelProgramStruct:
+    """C image of a ``gpytorch.kernels.KernelProgram`` (built once per program)."""
+    st = getattr(program, "_struct", None)
+    if st is not None:
+        return st
+    st = _KernelProgramStruct()
+    st.nleaf, st.nterm, st.nparam = len(program.leaves), len(program.terms), len(program.params)
+    for l, ((kind, mask, _), par) in enumerate(zip(program.leaves, program.leaf_par)):
+        st.kind[l], st.dims[l], st.par[l] = kind, mask, par
+    for t, ((lv, _), sc) in enumerate(zip(program.terms, program.term_scales)):
+        st.tmask[t] = sum(1 << l for l in lv)
+        st.tnscale[t] = len(sc)
+        for i, p in enumerate(sc):
+            st.tscale[t][i] = p
+    program._struct = st
+    return st
+
+
+def mll_kernel_value_grad(x, y, mean, noise, noise_scalar, program, theta, jitter=0.0, need_grad=True,
+                          workspace: Optional[Workspace] = None):
+    """One MLL evaluation of a composed stationary kernel (``program``: gpytorch.kernels.KernelProgram, ``theta`` its (P,)
+    constrained parameter values on the device) through pgm_mll_kernel_value_grad_f64.  x (n,d) y (n) mean (n)
+    noise (n)|None noise_scalar 0-dim tensor|float|None.  Returns dict(mll, g_theta, g_noise, g_mean, info, workspace)."""
+    require_gpu(x, "mll_kernel_value_grad")
+    dev = x.device
+    n = y.shape[-1]
+    xd = _dev64(x.reshape(n, -1), dev)
+    d = xd.shape[-1]
+    yd = _dev64(y.reshape(n), dev)
+    md = _dev64(mean.expand(y.shape).reshape(n), dev)
+    nz = None if noise is None else _dev64(noise.expand(y.shape).reshape(n), dev)
+    th = _dev64(theta.reshape(1, -1), dev)
+    P = th.shape[-1]
+    ns = None if noise_scalar is None else _dev64(torch.as_tensor(noise_scalar, device=dev).reshape(1), dev)
+    ws = workspace or get_workspace(dev, n, max(P, 4), d, 1)
+    out = dict(mll=torch.empty(1, dtype=torch.float64, device=dev), info=torch.zeros(1, dtype=torch.int32, device=dev))
+    if need_grad:
+        out.update(g_theta=torch.empty(P, dtype=torch.float64, device=dev), g_noise=torch.empty(n, dtype=torch.float64, device=dev),
+                   g_mean=torch.empty(n, dtype=torch.float64, device=dev))
+    st = kernel_program_struct(program)
+    with torch.cuda.device(dev):
+        rc = load().pgm_mll_kernel_value_grad_f64(ws.handle, 1, _ptr(xd), _ptr(yd), _ptr(md), _ptr(nz), _ptr(ns), n, d, byref(st), _ptr(th),
+                                                  float(jitter), 1 if need_grad else 0, _ptr(out["mll"]), _ptr(out.get("g_theta")),
+                                                  _ptr(out.get("g_noise")), _ptr(out.get("g_mean")), _ptr(out["info"]), current_stream_ptr(dev))
+    _check(rc, "pgm_mll_kernel_value_grad_f64")
+    out["_keep"] = (xd, yd, md, nz, ns, th)
+    out["mll"], out["info"] = out["mll"][0], out["info"][0]
     out["workspace"] = ws
     return out
 

@@ -8,6 +8,19 @@
 constexpr int PGM_MAX_QD = 16;      // Q*d the LDS staging is sized for
 constexpr int PGM_MAX_D = 2;
 
+// A composed stationary kernel as a sum of products of leaf kernels (pgm_generic.inc); mirrors pgm_kernel_program of the
+// C ABI.  Travels by value inside PgmDev (kernel arguments: decoding it touches no memory).
+constexpr int KP_MAXL = 6, KP_MAXT = 4, KP_MAXP = 12;
+struct KProg {
+  int nleaf, nterm, nparam;
+  unsigned char kind[KP_MAXL];       // leaf kind (KLeaf)
+  unsigned char dims[KP_MAXL];       // bit mask of the input dimensions the leaf sees
+  unsigned char par[KP_MAXL];        // index of the leaf's first parameter in theta
+  unsigned char tmask[KP_MAXT];      // leaves of term t (bit mask)
+  unsigned char tnscale[KP_MAXT];    // scale parameters of term t ...
+  unsigned char tscale[KP_MAXT][3];  // ... and their indices in theta
+};
+
 // Device view of one call (passed by value to every kernel).  All problems of a
 // batch share sizes; buffer b of a batch sits at base + b * stride.
 struct PgmDev {
@@ -38,6 +51,8 @@ struct PgmDev {
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
   double *mll, *g_w, *g_mu, *g_v, *g_noise, *g_mean;
   int* info_out;
+  int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
+  KProg prog;
 };
 
 enum PgmPhase { PH_PRE = 0, PH_BUILD, PH_DIAG, PH_TRSM, PH_UPDATE, PH_LAUUM, PH_FINAL, PH_FUSED, PH_COUNT };
@@ -73,7 +88,7 @@ struct pgm_ws {
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;
-  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; hipGraphExec_t exec; };
+  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
   // profiling
   bool prof_on;

@@ -1586,6 +1586,8 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
   if (t == 0) F.it[0] = it + 1;
 }
 
+#include "pgm_generic.inc"
+
 }  // namespace
 
 // ===========================================================================

@@ -78,6 +78,16 @@ class MultivariateNormal(Distribution):
             per_datum = sm_exact_mll(c.x1, value, self.loc, c.noise_vec, c.noise_scalar,
                                      k.mixture_weights, k.mixture_means, k.mixture_scales, k.dim_order)
             return per_datum * n
+        if isinstance(c, DenseCovariance) and c.fused and value.dim() == 1:
+            # a composed stationary kernel with a device program: build, sweep and gradient contraction fused (no N x N
+            # matrix in torch); anything else below takes the matrix torch builds through the dense back-end
+            from ..mll_function import kernel_exact_mll
+            n = value.shape[-1]
+            prog = c.program
+            ns = c.noise_scalar
+            if ns is not None and not torch.is_tensor(ns):
+                ns = torch.as_tensor(ns, dtype=value.dtype, device=value.device)
+            return kernel_exact_mll(prog, c.x, value, self.loc, c.noise_vec, ns, prog.theta()) * n
         if isinstance(c, DenseCovariance) and c.is_square:
             # any other kernel: the matrix torch built goes through the same factorisation sweep (dense back-end)
             from ..mll_function import dense_exact_mll

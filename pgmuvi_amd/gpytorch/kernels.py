@@ -74,6 +74,15 @@ class Kernel(Module):
     def __call__(self, x1, x2=None, diag=False, **params):
         from .lazy import DenseCovariance
         square = x2 is None or x2 is x1
+        if square and not diag and self.training and type(self).forward is Kernel.forward:
+            # training-mode K(x, x) of a composed stationary kernel: left unevaluated with its compiled program, so that
+            # ``mll(output, y)`` can take the fused generic-kernel path (pgm_mll_kernel_value_grad_f64)
+            xs = x1.unsqueeze(1) if x1.ndimension() == 1 else x1
+            if xs.ndimension() == 2:
+                prog = compile_program(self, xs.shape[-1])
+                if prog is not None:
+                    # (``x`` stays the full input: the program's leaves carry the column masks of every active_dims on the way)
+                    return DenseCovariance(None, True, kernel=_FullInput(self), x=xs, program=prog)
         x1 = self._select(x1)
         x2 = x1 if x2 is None else self._select(x2)
         out = self.forward(x1, x2, diag=diag, **params)
@@ -90,6 +99,166 @@ class Kernel(Module):
     @property
     def is_stationary(self):
         return self.has_lengthscale
+
+
+class _FullInput:
+    """``forward(x, x)`` of a kernel applied to the FULL input (its own ``active_dims`` selected first): what a lazily held
+    ``DenseCovariance`` calls if somebody asks for the matrix after all."""
+
+    def __init__(self, kernel):
+        self.kernel = kernel
+
+    def forward(self, x1, x2):
+        k = self.kernel
+        return k.forward(k._select(x1), k._select(x2))
+
+
+# ---- composed stationary kernels as a device program (pgm_mll_kernel_value_grad_f64, csrc/pgm_generic.inc) ----------------
+KP_MAXL, KP_MAXT, KP_MAXP = 6, 4, 12
+_LEAF_KINDS = {"rbf": 1, "matern0.5": 2, "matern1.5": 3, "matern2.5": 4, "periodic": 5, "rq": 6, "cosine": 7, "linear": 8,
+               "constant": 9}
+
+
+class KernelProgram:
+    """Sum-of-products expansion of a kernel tree: ``leaves`` [(kind, dims mask, [(module, attribute), ...])], ``terms``
+    [(leaf indices, [(module, attribute) of the scale factors])], ``params`` the distinct (module, attribute) pairs in theta
+    order.  ``theta()`` stacks the constrained parameter values (with autograd history); ``struct`` is the C-ABI image."""
+
+    def __init__(self, leaves, terms, params, d):
+        self.leaves, self.terms, self.params, self.d = leaves, terms, params, d
+        index = {(id(m), a): i for i, (m, a) in enumerate(params)}
+        self.leaf_par = [index[(id(ps[0][0]), ps[0][1])] for _, _, ps in leaves]
+        self.term_scales = [[index[(id(m), a)] for m, a in sc] for _, sc in terms]
+
+    def theta(self):
+        return torch.stack([getattr(m, a).reshape(()) for m, a in self.params])
+
+    @property
+    def key(self):
+        return (self.d, tuple((k, dm, p) for (k, dm, _), p in zip(self.leaves, self.leaf_par)),
+                tuple((tuple(lv), tuple(sc)) for (lv, _), sc in zip(self.terms, self.term_scales)), len(self.params))
+
+
+def _leaf_of(k):
+    """(kind, [(module, attribute)]) of a leaf kernel the device program knows, else None."""
+    def single(t):
+        return t is not None and t.numel() == 1
+    if type(k) is RBFKernel and single(k.raw_lengthscale):
+        return "rbf", [(k, "lengthscale")]
+    if type(k) is MaternKernel and single(k.raw_lengthscale):
+        return f"matern{k.nu}", [(k, "lengthscale")]
+    if type(k) is PeriodicKernel and single(k.raw_lengthscale) and single(k.raw_period_length):
+        return "periodic", [(k, "period_length"), (k, "lengthscale")]
+    if type(k) is RQKernel and single(k.raw_lengthscale) and single(k.raw_alpha):
+        return "rq", [(k, "lengthscale"), (k, "alpha")]
+    if type(k) is CosineKernel and single(k.raw_period_length):
+        return "cosine", [(k, "period_length")]
+    if type(k) is LinearKernel and single(k.raw_variance):
+        return "linear", [(k, "variance")]
+    if type(k) is ConstantKernel and single(k.raw_constant):
+        return "constant", [(k, "constant")]
+    return None
+
+
+def _tree_signature(k):
+    """Cheap structural fingerprint of a kernel tree (modules, classes, active_dims, parameter sizes): the compiled program of
+    a model is reused across iterations as long as this does not change."""
+    ad = getattr(k, "active_dims", None)
+    sig = [id(k), type(k).__name__, None if ad is None else tuple(int(i) for i in ad.reshape(-1).tolist()),
+           tuple(p.numel() for p in k._parameters.values() if p is not None)]
+    for sub in ([k.base_kernel] if hasattr(k, "base_kernel") else list(getattr(k, "kernels", []))):
+        sig.append(_tree_signature(sub))
+    return tuple(sig)
+
+
+def compile_program(kernel, d):
+    """Cached ``_compile_program``: one compilation per kernel tree and input width."""
+    sig = (d, _tree_signature(kernel))
+    cached = kernel.__dict__.get("_program_cache")
+    if cached is not None and cached[0] == sig:
+        return cached[1]
+    prog = _compile_program(kernel, d)
+    kernel.__dict__["_program_cache"] = (sig, prog)
+    return prog
+
+
+def _compile_program(kernel, d):
+    """``KernelProgram`` of ``kernel`` on ``d``-column inputs, or None when the tree holds something the device program does
+    not cover (then the matrix is built by torch and goes through the dense back-end): a leaf other than RBF / Matern /
+    periodic / RQ / cosine / linear / constant with one lengthscale, batch shapes, more than 6 leaves, 4 product terms, 12
+    parameters or 3 scale factors per term, d > 2."""
+    if d < 1 or d > 2:
+        return None
+    leaves, leaf_ids = [], {}
+
+    def cols_of(k, cols):
+        if getattr(k, "active_dims", None) is None:
+            return cols
+        idx = [int(i) for i in k.active_dims.reshape(-1).tolist()]
+        if any(i >= len(cols) for i in idx):
+            return None
+        return [cols[i] for i in idx]
+
+    def expand(k, cols):
+        if len(tuple(getattr(k, "batch_shape", ()))) != 0:
+            return None
+        cols = cols_of(k, cols)
+        if cols is None:
+            return None
+        if type(k) is ScaleKernel:
+            if k.raw_outputscale.numel() != 1:
+                return None
+            base = expand(k.base_kernel, cols)
+            return None if base is None else [(lv, sc + [(k, "outputscale")]) for lv, sc in base]
+        if type(k) is AdditiveKernel:
+            out = []
+            for sub in k.kernels:
+                t = expand(sub, cols)
+                if t is None:
+                    return None
+                out += t
+            return out
+        if type(k) is ProductKernel:
+            out = [([], [])]
+            for sub in k.kernels:
+                t = expand(sub, cols)
+                if t is None:
+                    return None
+                out = [(a + lv, b + sc) for a, b in out for lv, sc in t]
+                if len(out) > KP_MAXT:
+                    return None
+            return out
+        leaf = _leaf_of(k)
+        if leaf is None:
+            return None
+        kind, pars = leaf
+        mask = sum(1 << c for c in set(cols))
+        if mask == 0 and kind != "constant":
+            return None
+        key = (id(k), mask)
+        if key not in leaf_ids:
+            leaf_ids[key] = len(leaves)
+            leaves.append((_LEAF_KINDS[kind], mask, pars))
+        return [([leaf_ids[key]], [])]
+
+    terms = expand(kernel, list(range(d)))
+    if not terms or len(terms) > KP_MAXT or len(leaves) > KP_MAXL:
+        return None
+    if any(len(set(lv)) != len(lv) or len(sc) > 3 or not lv for lv, sc in terms):      # (k * k of one module: not a product of distinct leaves)
+        return None
+    params, seen = [], set()
+    for _, _, pars in leaves:                     # a leaf's parameters are consecutive in theta
+        for m, a in pars:
+            if (id(m), a) in seen:
+                return None
+            seen.add((id(m), a)); params.append((m, a))
+    for _, sc in terms:
+        for m, a in sc:
+            if (id(m), a) not in seen:
+                seen.add((id(m), a)); params.append((m, a))
+    if len(params) > KP_MAXP:
+        return None
+    return KernelProgram(leaves, terms, params, d)
 
 
 def _sq_dist(a, b):

@@ -66,9 +66,23 @@ class DenseCovariance:
     """A covariance matrix torch has built (any kernel but the fused spectral-mixture one), with autograd history;
     noise is kept apart so that ``to_dense`` adds it to the diagonal once."""
 
-    def __init__(self, K, square, noise_vec=None, noise_scalar=None):
-        self.K, self.square = K, square
+    def __init__(self, K, square, noise_vec=None, noise_scalar=None, kernel=None, x=None, program=None):
+        # ``K`` None: the matrix of ``kernel`` on ``x`` (square), evaluated by torch only if somebody asks for it; with a
+        # compiled ``program`` the training-mode log-likelihood never does (fused generic-kernel path, kernels.compile_program)
+        self._K, self.square = K, square
         self.noise_vec, self.noise_scalar = noise_vec, noise_scalar
+        self.kernel, self.x, self.program = kernel, x, program
+
+    @property
+    def K(self):
+        if self._K is None:
+            self._K = self.kernel.forward(self.x, self.x)
+        return self._K
+
+    @property
+    def fused(self):
+        """Can the training-mode log-likelihood take the fused generic-kernel path (nothing has materialised K)?"""
+        return self.program is not None and self._K is None and self.square
 
     @property
     def is_square(self):
@@ -76,10 +90,13 @@ class DenseCovariance:
 
     @property
     def shape(self):
+        if self._K is None:
+            n = self.x.shape[-2]
+            return torch.Size([n, n])
         return self.K.shape
 
     def size(self, dim=None):
-        return self.K.shape if dim is None else self.K.shape[dim]
+        return self.shape if dim is None else self.shape[dim]
 
     def add_noise(self, noise_vec=None, noise_scalar=None):
         nv, ns = self.noise_vec, self.noise_scalar
@@ -87,7 +104,7 @@ class DenseCovariance:
             nv = noise_vec if nv is None else nv + noise_vec
         if noise_scalar is not None:
             ns = noise_scalar if ns is None else ns + noise_scalar
-        return DenseCovariance(self.K, self.square, nv, ns)
+        return DenseCovariance(self._K, self.square, nv, ns, self.kernel, self.x, self.program)
 
     def to_dense(self):
         K = self.K

@@ -19,7 +19,7 @@ astropy's rule: ``'auto'`` (the default, what pgmuvi calls) takes the FFT approx
 grid of more than 200 frequencies -- ``pgm_lomb_scargle_fast_f64``: samples spread onto an oversampled grid, inverse FFTs,
 the tau form -- and the exact sums otherwise; ``'fast'`` / ``'slow'`` force one or the other.  The approximation is what
 the reference's recorded outputs contain: it differs from the exact sums by up to 1e-2 in the power at the high-frequency
-end and reorders near-equal peaks (``oracle/ls_oracle.py``).  The false-alarm formulas (Baluev 2008) are restated from
+end and reorders near-equal peaks.  The false-alarm formulas (Baluev 2008) are restated from
 astropy's published implementation -- unverified against an installed astropy.
 """
 from __future__ import annotations

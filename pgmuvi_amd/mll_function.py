@@ -108,6 +108,66 @@ def _evaluate_dense(A, r, need_grad):
     raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
 
 
+def _evaluate_kernel(x, y, mean, noise_vec, noise_scalar, program, theta, need_grad):
+    """The fused generic-kernel evaluation with the same jitter-retry policy as ``_evaluate``."""
+    out = _hip.mll_kernel_value_grad(x, y, mean, noise_vec, noise_scalar, program, theta, 0.0, need_grad)
+    if settings.check_cholesky_info.off() or not bool(out["info"] != 0):
+        return out, 0.0
+    if bool(torch.isnan(y).any()) or bool(torch.isnan(theta).any()):
+        raise NanError("cholesky: NaN in the inputs of the marginal log likelihood.")
+    base = settings.cholesky_jitter.value(torch.float64)
+    jitter = 0.0
+    for i in range(settings.cholesky_max_tries.value()):
+        jitter = base * (10 ** i)
+        warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
+        out = _hip.mll_kernel_value_grad(x, y, mean, noise_vec, noise_scalar, program, theta, jitter, need_grad)
+        if not bool(out["info"] != 0):
+            return out, jitter
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
+
+
+class KernelExactMLLFunction(torch.autograd.Function):
+    """mll per datum = log N(y | mean, K_theta(x, x) + diag(noise_vec) + noise_scalar I) / N for a composed stationary kernel
+    given as a device program (gpytorch.kernels.compile_program): matrix build, factorisation and the contraction of
+    d mll / d theta in one C-ABI call -- no N x N matrix in torch, no autograd graph over one."""
+
+    @staticmethod
+    def forward(ctx, program, x, y, mean, noise_vec, noise_scalar, theta):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradients with respect to the inputs x are not part of the hot path")
+        need_grad = any(ctx.needs_input_grad)
+        out, jitter = _evaluate_kernel(x, y, mean, noise_vec, noise_scalar, program, theta, need_grad)
+        ctx.shapes = (y.shape, mean.shape, None if noise_vec is None else noise_vec.shape,
+                      None if noise_scalar is None else noise_scalar.shape, theta.shape)
+        ctx.dtypes = (y.dtype, mean.dtype, None if noise_vec is None else noise_vec.dtype,
+                      None if noise_scalar is None else noise_scalar.dtype, theta.dtype)
+        if need_grad:
+            ctx.save_for_backward(out["g_theta"], out["g_noise"], out["g_mean"])
+        KernelExactMLLFunction.last_jitter = jitter
+        return out["mll"].to(theta.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g_theta, g_noise, g_mean = ctx.saved_tensors
+        ys, ms, nvs, nss, ths = ctx.shapes
+        yd, md, nvd, nsd, thd = ctx.dtypes
+        go = gout.to(torch.float64)
+        need = ctx.needs_input_grad
+        gy = (-(g_mean * go)).reshape(ys).to(yd) if need[2] else None
+        gm = (g_mean * go).reshape(ys).sum_to_size(ms).to(md) if need[3] else None
+        gnv = (g_noise * go).reshape(ys).sum_to_size(nvs).to(nvd) if (nvs is not None and need[4]) else None
+        gns = (g_noise.sum() * go).reshape(nss if len(nss) else ()).to(nsd) if (nss is not None and need[5]) else None
+        gth = (g_theta * go).reshape(ths).to(thd) if need[6] else None
+        return None, None, gy, gm, gnv, gns, gth
+
+
+KernelExactMLLFunction.last_jitter = 0.0
+
+
+def kernel_exact_mll(program, x, y, mean, noise_vec, noise_scalar, theta):
+    return KernelExactMLLFunction.apply(program, x, y, mean, noise_vec, noise_scalar, theta)
+
+
 class DenseExactMLLFunction(torch.autograd.Function):
     """mll per datum = log N(r | 0, A) / N for a dense symmetric A: the factorisation sweep of the hot path on a matrix
     built elsewhere; backward hands dmll/dA = (alpha alpha^T - A^-1) / 2N and dmll/dr = -alpha / N to autograd."""

@@ -112,6 +112,34 @@ def lomb_scargle_fast_by_exact_sums(t, y, dy, f0, df, nf, fit_mean=True, center_
                         torch.as_tensor(f0 + df * np.arange(nf), dtype=torch.float64), fit_mean, center_data)
 
 
+def mll_kernel_value_grad(x, y, mean, noise, noise_scalar, program, theta, jitter=0.0, need_grad=True, workspace=None):
+    """TEST-ONLY stand-in for ``pgmuvi_amd._hip.mll_kernel_value_grad``: the program's matrix by the oracle's torch
+    formulas, value by a torch Cholesky, every gradient by autograd."""
+    D = torch.float64
+    n = y.shape[-1]
+    leaves = [(k, m, p) for (k, m, _), p in zip(program.leaves, program.leaf_par)]
+    terms = [(lv, sc) for (lv, _), sc in zip(program.terms, program.term_scales)]
+    th = theta.detach().to(D).reshape(-1).clone().requires_grad_(True)
+    mu = mean.detach().to(D).expand(n).clone().requires_grad_(True)
+    nv = (torch.zeros(n, dtype=D) if noise is None else noise.detach().to(D).expand(n).clone())
+    if noise_scalar is not None:
+        nv = nv + torch.as_tensor(noise_scalar).detach().to(D)
+    nv = nv.clone().requires_grad_(True)
+    try:
+        with torch.enable_grad():
+            K = orc.kernel_program_matrix(leaves, terms, th, x.detach().to(D).reshape(n, -1))
+            val = orc.mll_dense(K, y.detach().to(D), mu, nv, jitter)
+            val.backward()
+        out = dict(mll=val.detach(), g_theta=th.grad, g_noise=nv.grad, g_mean=mu.grad, info=torch.tensor(0, dtype=torch.int32))
+    except torch.linalg.LinAlgError:
+        z = torch.zeros
+        out = dict(mll=torch.tensor(float("nan"), dtype=D), g_theta=z(th.numel(), dtype=D), g_noise=z(n, dtype=D), g_mean=z(n, dtype=D),
+                   info=torch.tensor(1, dtype=torch.int32))
+    out = {k: t.to(y.device) for k, t in out.items()}
+    out["workspace"] = None
+    return out
+
+
 def mll_dense(A, r, jitter=0.0, need_grad=True, workspace=None):
     """TEST-ONLY stand-in for ``pgmuvi_amd._hip.mll_dense``: value by a torch Cholesky, gradients by autograd."""
     batched = A.dim() == 3

@@ -16,7 +16,7 @@ except Exception:                                              # a real astropy 
     pass
 import torch
 
-for _name in ("predict", "lomb_scargle", "mll_dense", "predict_dense"):
+for _name in ("predict", "lomb_scargle", "lomb_scargle_fast", "mll_dense", "mll_kernel_value_grad", "predict_dense"):
     setattr(_hip, _name, getattr(ob, _name))
 _hip.mll_value_grad = ob.mll_value_grad_remember              # (the predict stand-in needs the last evaluation's inputs)
 _hip.require_gpu = lambda *a, **k: None

@@ -93,7 +93,7 @@ def test_dense_mll_backward_and_prediction_with_standins():
     for lik in (g.likelihoods.FixedNoiseGaussianLikelihood(noise), g.likelihoods.GaussianLikelihood().double()):
         m = _matern_model(x, y, lik)
         m.train(); lik.train()
-        with mock.patch.object(_hip, "mll_dense", ob.mll_dense), mock.patch.object(_hip, "require_gpu", lambda *a, **k: None):
+        with mock.patch.object(_hip, "mll_dense", ob.mll_dense), mock.patch.object(_hip, "mll_kernel_value_grad", ob.mll_kernel_value_grad), mock.patch.object(_hip, "require_gpu", lambda *a, **k: None):
             mll = g.mlls.ExactMarginalLogLikelihood(lik, m)
             loss = -mll(m(x), y)
             loss.backward()
@@ -112,7 +112,7 @@ def test_dense_mll_backward_and_prediction_with_standins():
     m = _matern_model(x, y, lik)
     m.eval(); lik.eval()
     xs = torch.linspace(float(x.min()), float(x.max()), 40, dtype=D)
-    with mock.patch.object(_hip, "mll_dense", ob.mll_dense), mock.patch.object(_hip, "predict_dense", ob.predict_dense), torch.no_grad():
+    with mock.patch.object(_hip, "mll_dense", ob.mll_dense), mock.patch.object(_hip, "mll_kernel_value_grad", ob.mll_kernel_value_grad), mock.patch.object(_hip, "predict_dense", ob.predict_dense), torch.no_grad():
         pred = m(xs)
     ls = math.log(2.0)
     Kxx, Kxs = ls * orc.matern(x, x, 25.0, 1.5), ls * orc.matern(x, xs, 25.0, 1.5)
@@ -140,7 +140,7 @@ def test_reference_non_sm_models_train_through_the_shim():
         from pgmuvi_amd.trainers import train      # (the reference's loop needs a Lightcurve for its results bookkeeping)
         t, y, e = syn.cfg2(n_obs=50)
         x, y, nz = t.double(), y.double(), e.double() ** 2
-        with mock.patch.object(_hip, "mll_dense", ob.mll_dense), mock.patch.object(_hip, "require_gpu", lambda *a, **k: None):
+        with mock.patch.object(_hip, "mll_dense", ob.mll_dense), mock.patch.object(_hip, "mll_kernel_value_grad", ob.mll_kernel_value_grad), mock.patch.object(_hip, "require_gpu", lambda *a, **k: None):
             for make in (lambda l: gps.MaternGPModel(x, y, l, nu=1.5), lambda l: gps.QuasiPeriodicGPModel(x, y, l, period=150.0),
                          lambda l: gps.PeriodicPlusStochasticGPModel(x, y, l, period=150.0)):
                 lik = gpytorch.likelihoods.FixedNoiseGaussianLikelihood(nz)

@@ -847,6 +847,117 @@ def test_dense_backend_vs_oracle(dev):
     assert torch.allclose(pred.mean.cpu(), pm, atol=1e-8) and torch.allclose(pred.variance.cpu(), pv, atol=1e-8)
 
 
+def _kernel_zoo(d):
+    """Composed stationary kernels of the reference's alternative models (pgmuvi/gps.py:915-1342) and the rest of the leaf set."""
+    K = g.kernels
+    def qp():
+        per, rbf = K.PeriodicKernel(), K.RBFKernel()
+        per.period_length = 37.0; per.lengthscale = 1.3; rbf.lengthscale = 180.0
+        sk = K.ScaleKernel(K.ProductKernel(per, rbf)); sk.outputscale = 0.8
+        return sk
+    def scaled(base, ls, osc, **kw):
+        base.lengthscale = ls
+        for k_, v_ in kw.items():
+            setattr(base, k_, v_)
+        sk = K.ScaleKernel(base); sk.outputscale = osc
+        return sk
+    zoo = {
+        "matern0.5": scaled(K.MaternKernel(nu=0.5), 25.0, 1.1),
+        "matern1.5": scaled(K.MaternKernel(nu=1.5), 25.0, 0.9),
+        "matern2.5": scaled(K.MaternKernel(nu=2.5), 40.0, 1.3),
+        "rbf": scaled(K.RBFKernel(), 30.0, 0.7),
+        "rq": scaled(K.RQKernel(), 30.0, 0.7, alpha=1.7),
+        "quasi_periodic": qp(),
+        "periodic_plus_stochastic": K.AdditiveKernel(qp(), scaled(K.RBFKernel(), 8.0, 0.3)),
+    }
+    cos = K.CosineKernel(); cos.period_length = 55.0
+    zoo["cosine_times_rbf_plus_constant"] = K.AdditiveKernel(K.ProductKernel(cos, scaled(K.RBFKernel(), 90.0, 0.6)), K.ConstantKernel())
+    lin = K.LinearKernel(); lin.variance = 2e-5
+    zoo["linear_times_matern"] = K.ProductKernel(lin, scaled(K.MaternKernel(nu=1.5), 60.0, 0.5))
+    if d == 2:
+        tk, wk = scaled(K.MaternKernel(nu=1.5), 20.0, 0.9), scaled(K.RBFKernel(), 0.8, 1.2)
+        tk.register_buffer("active_dims", torch.tensor([0])); wk.register_buffer("active_dims", torch.tensor([1]))
+        zoo = {"separable": K.ProductKernel(tk, wk), "qp_both_dims": qp(), "rq_2d": scaled(K.RQKernel(), 9.0, 0.8, alpha=0.9)}
+        ak, ck = qp(), K.ConstantKernel()
+        ak.register_buffer("active_dims", torch.tensor([0])); ck.register_buffer("active_dims", torch.tensor([1]))
+        zoo["achromatic"] = K.ProductKernel(ak, ck)
+    return {k: v.double() for k, v in zoo.items()}
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_generic_kernel_programs_vs_oracle(dev, d):
+    """pgm_mll_kernel_value_grad_f64 -- build, sweep and gradient contraction fused for composed stationary kernels -- against
+    the oracle's torch formulas with autograd: every leaf kind, sums / products / scales, active_dims in 2-D, ragged sizes,
+    the fused sweep with the early inverse pass (N = 1500) and a failed factorisation."""
+    import _oracle_backend as ob
+    from pgmuvi_amd.gpytorch.kernels import compile_program
+    for name, kern in _kernel_zoo(d).items():
+        prog = compile_program(kern, d)
+        assert prog is not None, name
+        theta = prog.theta().detach()
+        for n in ((5, 130, 700, 1500) if name in ("quasi_periodic", "separable", "periodic_plus_stochastic") else (300,)):
+            gen = torch.Generator().manual_seed(n + d)
+            x = torch.rand(n, d, generator=gen, dtype=D) * torch.tensor([300.0, 2.0][:d], dtype=D)
+            x = x[torch.argsort(x[:, 0])]
+            y = torch.randn(n, generator=gen, dtype=D)
+            nz = 0.02 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+            mean = torch.full((n,), 0.1, dtype=D)
+            out = _hip.mll_kernel_value_grad(x.to(dev), y.to(dev), mean.to(dev), nz.to(dev), torch.tensor(0.01, dtype=D, device=dev), prog, theta.to(dev))
+            ref = ob.mll_kernel_value_grad(x, y, mean, nz, torch.tensor(0.01, dtype=D), prog, theta)
+            assert int(out["info"]) == 0 and abs(float(out["mll"]) - float(ref["mll"])) < MLL_TOL, (name, n)
+            assert _rel(out["g_theta"], ref["g_theta"]) < GRAD_RTOL, (name, n, out["g_theta"], ref["g_theta"])
+            assert _rel(out["g_noise"], ref["g_noise"]) < GRAD_RTOL and _rel(out["g_mean"], ref["g_mean"]) < GRAD_RTOL, (name, n)
+            val_only = _hip.mll_kernel_value_grad(x.to(dev), y.to(dev), mean.to(dev), nz.to(dev), torch.tensor(0.01, dtype=D, device=dev), prog,
+                                                  theta.to(dev), need_grad=False)
+            assert float(val_only["mll"]) == float(out["mll"])
+    bad = _hip.mll_kernel_value_grad(x.to(dev), y.to(dev), mean.to(dev), torch.full((n,), -5.0, dtype=D, device=dev), None, prog, theta.to(dev))
+    assert int(bad["info"]) > 0 and torch.isnan(bad["mll"]) and torch.isnan(bad["g_theta"]).all()
+
+
+def test_generic_kernel_models_through_the_surface(dev):
+    """``model(x) -> mll -> backward`` of the reference's quasi-periodic and separable model shapes on the fused generic path:
+    loss and every raw-parameter gradient equal the same model evaluated through the dense back-end (the matrix built by
+    torch, differentiated by autograd); outside the program's reach (ARD lengthscales) the dense route is taken silently."""
+    t, y, e = syn.cfg2(n_obs=600)
+    x, yy, nz = t.double().to(dev), y.double().to(dev), (e.double() ** 2).to(dev)
+    X4, Y4, E4 = syn.cfg4(n_per_band=60)
+    cases = [("quasi_periodic", x, yy, nz, 1), ("periodic_plus_stochastic", x, yy, nz, 1),
+             ("separable", X4.double().to(dev), Y4.double().to(dev), (E4.double() ** 2).to(dev), 2)]
+    for name, xx, yv, nv, d in cases:
+        grads = {}
+        for route in ("fused", "dense"):
+            kern = _kernel_zoo(d)[name]
+            lik = g.likelihoods.FixedNoiseGaussianLikelihood(nv)
+
+            class Model(g.models.ExactGP):
+                def __init__(self):
+                    super().__init__(xx, yv, lik)
+                    self.mean_module = g.means.ConstantMean()
+                    self.covar_module = kern
+
+                def forward(self, xq):
+                    return g.distributions.MultivariateNormal(self.mean_module(xq), self.covar_module(xq))
+
+            m = Model().double().to(dev)
+            m.train(); lik.train()
+            mll = g.mlls.ExactMarginalLogLikelihood(lik, m)
+            out = m(xx)
+            c = out.lazy_covariance_matrix
+            assert c.fused
+            if route == "dense":
+                _ = c.K                                           # materialise: the log-likelihood then takes the dense back-end
+                assert not c.fused
+            loss = -mll(out, yv)
+            loss.backward()
+            grads[route] = (float(loss.detach()), {n_: p.grad.detach().clone() for n_, p in m.named_parameters()})
+        assert abs(grads["fused"][0] - grads["dense"][0]) < MLL_TOL, name
+        for n_ in grads["fused"][1]:
+            assert _rel(grads["fused"][1][n_], grads["dense"][1][n_]) < 1e-6, (name, n_)
+    ard = g.kernels.ScaleKernel(g.kernels.RBFKernel(ard_num_dims=2)).double().to(dev)
+    ard.train()
+    assert not ard(X4.double().to(dev)).fused
+
+
 def test_native_fit_loop_equals_the_host_loop(dev):
     """SURVEY.md section 8f row 2, all on the device (pgm_fit_*): transforms, evaluation, chain rule, optimiser step and log
     as one hipGraph replay per iteration follow the trajectory of the reference-shaped ``train`` (torch optimisers, autograd
