@@ -51,6 +51,9 @@ struct PgmDev {
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
   double *mll, *g_w, *g_mu, *g_v, *g_noise, *g_mean;
   int* info_out;
+  int ainv_from_tiles; // k-blocks per work item (0 = off): diag(A^-1) is taken from the accumulators of the (j, j) tiles' work items
+                      //    in the inverse/gradient launch (item number s of the tile -> dpart row s) and the separate column-sum
+                      //    pass over V is skipped
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
   KProg prog;
 };

@@ -878,6 +878,20 @@ __device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, 
   if (half == 0) P.dpart[b * P.sDpart + (int64_t)sp * P.np + jb * NB + c] = s + red[c];
 }
 
+// diag(A^-1) straight from the work items of the (j, j) tiles of A^-1: the lanes that hold diagonal elements write this item's
+// share to its row of dpart (item number = k-blocks before it / k-blocks per item); k_finalize sums the rows the tile has
+template <class C>
+__device__ __forceinline__ void ainv_diag_from_tile(const PgmDev& P, int b, int j, int p0, const v4d (&acc)[C::TM][C::TN]) {
+  const WavePos wp = wave_pos<C>();
+  if (wp.m0 != wp.n0) return;
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if ((wp.lane >> 4) + 4 * r == (wp.lane & 15))
+        P.dpart[b * P.sDpart + (int64_t)((p0 - j) / P.ainv_from_tiles) * P.np + j * NB + acc_col<C>(wp, ti)] = acc[ti][ti][r];
+}
+
 // The same items as a launch of their own: big batches of small problems have tens of thousands of them, and inside the
 // inverse/gradient launch they would run at its occupancy (two workgroups per CU, 64 KB of LDS each).
 __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
@@ -924,6 +938,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
     if (sacc == 1.2345e300) P.partials[0] = 1.0; }
   return;
 #endif
+  if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc);
   // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
   const int Q = P.q;
   constexpr int QC = (EPI_SLOTS - D) / (3 * D);          // mixtures staged at once
@@ -1099,8 +1114,13 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
       const double al = P.alpha[b * P.sVec + i];
       P.out_gmean[b * P.sVec + i] = al / (double)P.n;
       double dsum = 0.0;
+      if (P.ainv_from_tiles) {
+        const int cnt = (P.nb - i / NB + P.ainv_from_tiles - 1) / P.ainv_from_tiles;      // work items of tile (jb, jb)
+        for (int sp = 0; sp < cnt; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
+      } else {
 #pragma unroll
-      for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
+        for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
+      }
       P.out_gnoise[b * P.sVec + i] = half_n * (al * al - dsum);
     }
     return;

@@ -685,6 +685,9 @@ def test_config3_per_gpu_shard_of_64(dev):
         assert abs(float(val) - float(ll[i])) < MLL_TOL
         for p_ in ("w", "mu", "v"):
             assert _rel(out[f"g_{p_}"][i].reshape(-1), gr[p_].reshape(-1)) < GRAD_RTOL
+        # (batches take diag(A^-1), i.e. the noise gradient, from the accumulators of the (j, j) tiles of the inverse pass)
+        assert _rel(out["g_noise"][i], gr["noise"]) < GRAD_RTOL and _rel(out["g_mean"][i], gr["mean"]) < GRAD_RTOL
+    assert torch.allclose(out["g_noise"], out24["g_noise"], rtol=1e-9, atol=1e-13)
 
 
 def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
