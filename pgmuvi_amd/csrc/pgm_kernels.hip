@@ -841,6 +841,17 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 #define PGM_BIG_PF 2            // two chunks in flight: 64 x N=2048 13.83 -> 13.64 ms, 8 x N=4096 12.27 -> 12.19 ms
 #endif
 using CfgBig = TileCfg<128, 128, 64, 64, PGM_BIG_PF>;
+#ifndef PGM_UPD_WAVES8
+#define PGM_UPD_WAVES8 0
+#endif
+#ifndef PGM_UPD_PF
+#define PGM_UPD_PF 2
+#endif
+#if PGM_UPD_WAVES8
+using CfgUpd = TileCfg<128, 128, 64, 32, PGM_UPD_PF, 512>;      // (experiment) 8 wavefronts per 128x128 tile
+#else
+using CfgUpd = CfgBig;
+#endif
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
@@ -1325,6 +1336,11 @@ __global__ __launch_bounds__(256) void k_probe_mfma(double* out, int iters) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) acc[u] = v4d{0.0, 0.0, 0.0, 0.0};
   double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+  if (iters < 0) {                                             // (tools: operands with busy mantissas, |iters| iterations)
+    iters = -iters;
+    a = __longlong_as_double(0x3ff0000000000000LL | ((0x9e3779b97f4a7c15ULL * (threadIdx.x + 1) + blockIdx.x) >> 12));
+    bb = __longlong_as_double(0x3fe0000000000000LL | ((0xc2b2ae3d27d4eb4fULL * (threadIdx.x + 7) + blockIdx.x) >> 12)) - 1.25;
+  }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(bb));
