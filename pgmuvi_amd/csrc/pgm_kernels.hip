@@ -734,21 +734,13 @@ __global__ __launch_bounds__(CfgHead::NT, 2) void k_update_rows(PgmDev P, int k_
   plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x);
 }
 
-// workgroups >= nslabs of the grid are planned trailing-update tiles riding on this launch's idle CUs
-__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan) {
-  using C = CfgTrsmChain;
-  __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
-  if ((int)blockIdx.x >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x - nslabs); return; }
-  int b = blockIdx.z, bx = blockIdx.x;
-  if ((int)gridDim.x == nslabs) xcd_batch_remap(bx, b);          // (no planned tiles in the grid: batches, panel sweep)
-  const int slab = bx & 3;
-  int jb = bx >> 2;
-  if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
+// one column slab (C::BN columns, slab number `slab`) of block (k, jb) of block row k:  C <- Uinv_kk^T C, in place, and the
+// slab's share of the forward substitution / alpha update
+template <class C>
+__device__ __forceinline__ void trsm_slab(const PgmDev& P, double* lds, double* zs, double (*red)[C::WN], int b, int k, int jb, int slab) {
   double* A = P.A + b * P.sA;
   double* Cb = A + (int64_t)k * NB * P.ld + jb * NB + slab * C::BN;
   const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
-  __shared__ double zs[NB];
-  __shared__ double red[C::NT / 64][C::WN];
   if (threadIdx.x < NB) zs[threadIdx.x] = P.z[b * P.sVec + k * NB + threadIdx.x];
   v4d acc[C::TM][C::TN];
   acc_zero<C>(acc);
@@ -779,6 +771,21 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
     const int64_t g = b * P.sVec + jb * NB + slab * C::BN + c;
     if (jb > k) P.r[g] -= tot; else P.alpha[g] += tot;
   }
+}
+
+// workgroups >= nslabs of the grid are planned trailing-update tiles riding on this launch's idle CUs
+__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan) {
+  using C = CfgTrsmChain;
+  __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
+  if ((int)blockIdx.x >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x - nslabs); return; }
+  int b = blockIdx.z, bx = blockIdx.x;
+  if ((int)gridDim.x == nslabs) xcd_batch_remap(bx, b);          // (no planned tiles in the grid: batches, panel sweep)
+  const int slab = bx & 3;
+  int jb = bx >> 2;
+  if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
+  __shared__ double zs[NB];
+  __shared__ double red[C::NT / 64][C::WN];
+  trsm_slab<C>(P, lds, zs, red, b, k, jb, slab);
 }
 
 // ---------------------------------------------------------------------------

@@ -115,9 +115,10 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
     iterations, so the per-iteration host synchronisation of the reference loop
     (``pgmuvi/trainers.py:184-195``) disappears.  Same arguments and ``results`` dictionary as
     :func:`train`; differences: the stop rule is evaluated every ``check_every`` iterations (on
-    exactly the same window as the reference, so at most ``check_every - 1`` extra iterations
-    run), a failed factorisation surfaces as a non-finite loss (``NanError``) instead of the
-    jitter retry, and ``optim`` must be one of the string choices.
+    exactly the same window as the reference; up to ``check_every - 1`` iterations run past it on
+    the device and are discarded -- the model ends at the stop iteration's parameters), a failed
+    factorisation surfaces as a non-finite loss (``NanError``, with the last good parameters
+    restored) instead of the jitter retry, and ``optim`` must be one of the string choices.
     """
     from .gpytorch import settings
     from .gpytorch.utils.errors import NanError
@@ -131,6 +132,9 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
         raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
     if not train_x.is_cuda:
         raise RuntimeError("train_device needs the model and data on the GPU")
+    # (constraint bounds registered after the model moved to the GPU are host tensors: inside the captured iteration their
+    #  transfer would be an illegal host-to-device copy)
+    model.to(train_x.device); likelihood.to(train_x.device)
     model.train(); likelihood.train()
     mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -197,6 +201,11 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                     par_hist[n][i].copy_(p.detach())
             host_loss = loss_hist[done:done + blk].cpu().numpy()          # the only synchronisation of the block
             if not np.isfinite(host_loss).all():
+                # the model goes back to the last parameters a finite loss produced (NaN gradients have stepped it since)
+                good = done + int(np.argmax(~np.isfinite(host_loss)))
+                with torch.no_grad():
+                    for n, p in named.items():
+                        p.copy_(par_hist[n][good - 1] if good > 0 else state[n])
                 raise NanError("non-finite loss in the device-resident loop (factorisation failed or NaN parameters)")
             for off in range(blk):
                 i = done + off
@@ -212,17 +221,19 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                     break
             done += blk
         n_done = len(results["loss"])
+        if n_done and n_done < done:              # stopped inside a block: the model ends at the stop iteration, like the reference's
+            with torch.no_grad():
+                for n, p in named.items():
+                    p.copy_(par_hist[n][n_done - 1])
         if lightcurve is None:
             for n in names:
                 h = par_hist[n][:n_done].cpu().numpy()
                 results[n].extend(list(h))
         else:
-            # the lightcurve's parameter view (constrained, transformed names) at the end of the run;
-            # the per-iteration history is available under the raw parameter names
-            for key, value in lightcurve.get_parameters().items():
-                results[key].append(value.cpu().detach().numpy())
-            for n in names:
-                results[n] = list(par_hist[n][:n_done].cpu().numpy())
+            # one entry per iteration under every key of the lightcurve's parameter view, as the reference's loop logs them
+            raw_hist = {n: par_hist[n][:n_done].cpu().numpy() for n in names}
+            for key, rows in _lightcurve_traces(lightcurve, raw_hist).items():
+                results[key].extend(rows)
     return results
 
 
@@ -329,44 +340,44 @@ def _native_fit_handle(model, likelihood, train_x, train_y, maxiter, lr, optim, 
     return fit, pieces, raw0
 
 
-def _lightcurve_traces(lightcurve, pieces, hist):
+def _lightcurve_traces(lightcurve, raw_hist):
     """Per-iteration values of every ``Lightcurve.get_parameters()`` key (``pgmuvi/lightcurve.py:8999-9077``) from the raw
-    history of the native loop: without data transforms the constrained values of all iterations come from one vectorised
-    constraint transform per parameter; with ``xtransform`` / ``ytransform`` set each row goes through ``get_parameters``."""
-    n_keep = hist.shape[0]
+    parameter histories of a device-resident loop (``raw_hist``: parameter name -> array (iterations, *shape)): without data
+    transforms the constrained values of all iterations come from one vectorised constraint transform per parameter; with
+    ``xtransform`` / ``ytransform`` set each iteration goes through ``get_parameters`` itself."""
     model = lightcurve.model
-    where, off = {}, 0
-    for mod, name in pieces:
-        p = getattr(mod, name)
-        where[id(p)] = (off, p.numel(), tuple(p.shape), mod, name, p)
-        off += p.numel()
+    named = dict(model.named_parameters())
+    n_keep = len(next(iter(raw_hist.values()))) if raw_hist else 0
     traces = {}
     plain = getattr(lightcurve, "xtransform", None) is None and getattr(lightcurve, "ytransform", None) is None
     if plain:
-        for pname, p in model.named_parameters():
-            o, cnt, shp, mod, name, _ = where[id(p)]
-            rows = torch.as_tensor(hist[:, o:o + cnt]).to(p.dtype).reshape((n_keep,) + shp)     # (the model's dtype, as get_parameters sees it)
+        for pname, p in named.items():
+            rows = torch.as_tensor(np.asarray(raw_hist[pname])).to(p.dtype).reshape((n_keep,) + tuple(p.shape))   # (the model's dtype, as get_parameters sees it)
             if "raw" in pname:
-                key = ".".join(c.lstrip("raw_") for c in pname.split("."))             # (the reference's own key rule)
-                con = getattr(mod, "_constraints", {}).get(name + "_constraint")
+                comps = pname.split(".")
+                key = ".".join(c.lstrip("raw_") for c in comps)                        # (the reference's own key rule)
+                mod = model
+                for c in comps[:-1]:
+                    mod = getattr(mod, c)
+                con = getattr(mod, "_constraints", {}).get(comps[-1] + "_constraint")
                 vals = rows if con is None else con.transform(rows)
             else:
                 key, vals = pname, rows
             arr = vals.detach().cpu().numpy()
             traces[key] = [arr[i] for i in range(n_keep)]
         return traces
-    keep = {id(v[5]): v[5].detach().clone() for v in where.values()}
+    keep = {n: p.detach().clone() for n, p in named.items()}
     try:
         for i in range(n_keep):
             with torch.no_grad():
-                for o, cnt, shp, _, _, p in where.values():
-                    p.copy_(torch.as_tensor(hist[i, o:o + cnt], dtype=p.dtype).reshape(shp).to(p.device))
+                for n, p in named.items():
+                    p.copy_(torch.as_tensor(np.asarray(raw_hist[n][i]), dtype=p.dtype).reshape(p.shape).to(p.device))
             for key, value in lightcurve.get_parameters().items():
                 traces.setdefault(key, []).append(value.cpu().detach().numpy())
     finally:
         with torch.no_grad():
-            for _, _, _, _, _, p in where.values():
-                p.copy_(keep[id(p)])
+            for n, p in named.items():
+                p.copy_(keep[n])
     return traces
 
 
@@ -450,7 +461,13 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                 o, cnt, shp = offsets[id(p)]
                 results[n_].extend([hist[i, o:o + cnt].reshape(shp).copy() for i in range(n_keep)])
         else:
-            for key, rows in _lightcurve_traces(lightcurve, pieces, hist[:n_keep]).items():
+            raw_hist, off = {}, 0
+            by_id = {id(p): n_ for n_, p in model.named_parameters()}
+            for mod, name in pieces:
+                p = getattr(mod, name)
+                raw_hist[by_id[id(p)]] = hist[:n_keep, off:off + p.numel()].reshape((n_keep,) + tuple(p.shape))
+                off += p.numel()
+            for key, rows in _lightcurve_traces(lightcurve, raw_hist).items():
                 results[key].extend(rows)
     finally:
         fit.close()

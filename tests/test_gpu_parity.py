@@ -1078,16 +1078,19 @@ def test_native_fit_loop_in_lightcurve_mode_logs_every_iteration(dev):
                         "covar_module.mixture_scales": h["v"].to(dev), "mean_module.constant": torch.tensor(0.1, dtype=D, device=dev)})
         return _LightcurveLike(m, lik, x, yy)
 
-    a, b = build(), build()
+    from pgmuvi_amd.trainers import train_device
+    a, b, c = build(), build(), build()
     ra = train(lightcurve=a, maxiter=30, lr=0.02, optim="AdamW", progress=False)
     rb = train_native(lightcurve=b, maxiter=30, lr=0.02, optim="AdamW", check_every=8)
-    assert set(ra) == set(rb) and len(rb["loss"]) == 30
-    for key in ra:
-        if key in ("loss", "delta_loss"):
-            continue
-        assert len(ra[key]) == len(rb[key]) == 31, key
-        for va, vb in zip(ra[key], rb[key]):
-            assert va.shape == vb.shape and np.allclose(va, vb, rtol=1e-8, atol=1e-12), key
+    rc = train_device(lightcurve=c, maxiter=30, lr=0.02, optim="AdamW", check_every=8)
+    for rx, tol in ((rb, 1e-8), (rc, 2e-5)):          # (train_device steps with torch's capturable AdamW: same trajectory to ~1e-6)
+        assert set(ra) == set(rx) and len(rx["loss"]) == 30
+        for key in ra:
+            if key in ("loss", "delta_loss"):
+                continue
+            assert len(ra[key]) == len(rx[key]) == 31, key
+            for va, vb in zip(ra[key], rx[key]):
+                assert va.shape == vb.shape and np.allclose(va, vb, rtol=tol, atol=0.1 * tol + 1e-10), key
 
 
 def test_native_fit_loop_with_the_default_priors(dev):
