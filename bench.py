@@ -2,7 +2,7 @@
 """bench.py -- marginal-log-likelihood evaluations/sec of the MI355X hot path.
 
     python bench.py --gpus N --steps K --warmup W [--batch B]                      # headline: weak scaling
-    python bench.py --gpus N --steps K --warmup W --total-batch B [--n 2048]       # strong scaling of one B-light-curve batch
+    python bench.py --gpus N --steps K --warmup W --total-batch B [--npoints 2048] # strong scaling of one B-light-curve batch
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A *step* is one pass of the hot path -- SM kernel build + blocked Cholesky MLL + full
@@ -199,7 +199,7 @@ class Harness:
 
     def fence(self):
         torch.cuda.synchronize()
-        if self.world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -213,7 +213,7 @@ class Harness:
             res = step()
         self.fence()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
-        if self.world > 1:
+        if dist.is_initialized():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), res
 
@@ -257,7 +257,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="weak scaling: light curves per GPU per step")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: light curves of the whole batch, sharded over the GPUs")
     ap.add_argument("--chunk", type=int, default=0, help="strong scaling: light curves per launch set (0: by memory, at most 64)")
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--n", "--npoints", dest="n", type=int, default=4096,
+                    help="points per light curve (behind torch.distributed.run spell it --npoints: '--n' is an ambiguous prefix there)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batched / strong-scaling side measurements")
@@ -272,8 +273,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # (PGM_BENCH_DIST=1: initialise RCCL even for a single rank -- lets a one-GPU box exercise the collective path)
+    if world > 1 or os.environ.get("PGM_BENCH_DIST") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     h = Harness(dev, world)
     n = args.n
@@ -305,7 +309,7 @@ def main():
                 result["parity"] = {"abs_dmll_vs_cpu_oracle": abs(first - cpu_val), "tolerance": 1e-4, "mll": first}
                 result["speedup_vs_cpu_baseline"] = round(res["evals_per_s"] / cb["value"], 1)
             print(json.dumps(result))
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -392,7 +396,7 @@ def main():
     if rank == 0:
         result.update(extra)
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

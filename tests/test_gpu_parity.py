@@ -1354,6 +1354,23 @@ def test_c_abi_from_a_c_caller(dev):
     assert "FAIL" not in r.stdout and r.stdout.count("OK") >= 10
 
 
+def test_bench_collective_path_on_rccl(dev):
+    """``bench.py`` launched the way the driver launches the multi-GPU runs (``python -m torch.distributed.run``), with one
+    rank and ``PGM_BENCH_DIST=1`` so that the process group is RCCL ("nccl") even on this one-GPU box: barrier, the
+    all_gather of the log-likelihoods of both modes and the max-over-ranks timing all go through the collective library."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGM_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+            "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    for extra, scaling in ((["--npoints", "1024", "--no-extra"], "weak"), (["--npoints", "512", "--total-batch", "24", "--chunk", "8"], "strong")):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["scaling"] == scaling and out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
 def test_performance_guards(dev):
     """Coarse timing guards (about 4x above what one MI355X measures, best of three) for the shapes a change to one schedule can break without
     any parity test noticing: one N=4096 light curve, a shard of 2048-point curves, thousands of short curves per call."""
