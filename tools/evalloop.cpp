@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < reps; ++r) run();
   hipStreamSynchronize(st);
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
-  std::vector<double> h(16 + 3 * (size_t)n + (size_t)B);
+  std::vector<double> h((16 + 3 * (size_t)n) * (size_t)B);       // (= the allocation of `out`)
   hipMemcpy(h.data(), out, 8 * h.size(), hipMemcpyDeviceToHost);
   double gs = 0.0, gn = 0.0;                                   // gradient fingerprints: hyper-parameters, per-point noise
   for (int a = 1; a < 1 + 3 * q && ng; ++a) gs += h[(size_t)(a < 1 + q ? a : (a < 1 + 2 * q ? 5 + a - 1 - q : 9 + a - 1 - 2 * q))] * (1.0 + 0.1 * a);
