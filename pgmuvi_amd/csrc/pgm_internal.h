@@ -70,6 +70,7 @@ struct pgm_ws {
   int4* items;           // device copy of the work-item table
   std::vector<int4> items_host;
   int items_nb, items_batch, items_count, items_cap, items_kc;
+  double items_epi, early_epi;  // epilogue weight the two work lists were split for (spectral mixture 3, generic kernels 15)
   // state of the last need_grad evaluation (for pgm_predict_f64)
   PgmDev last;
   bool last_valid;
