@@ -189,6 +189,17 @@ int pgm_lomb_scargle_f64(const double* t, const double* y, const double* dy, int
                          void* stream);
 
 /*
+ * Factorisation status of the last pgm_mll_value_grad*_f64 / pgm_mll_kernel_value_grad_f64 call on `ws`, as soon as it is
+ * final: waits for the event the library records after the factorisation sweep (NOT for the inverse/gradient pass that
+ * follows it on the stream) and returns 0 (every problem factored) or 1, with the per-problem LAPACK-style codes in
+ * info_host[batch] (host memory, may be NULL).  This is the host synchronisation GPyTorch's psd_safe_cholesky performs inside
+ * `mll(output, y)` (pgmuvi/trainers.py:180) to decide on a jitter retry; the caller's Python work between forward and
+ * backward then overlaps the rest of the evaluation.  <0: nothing to report (no evaluation yet, or it ran inside a stream
+ * capture of the caller).
+ */
+int pgm_factorisation_status(pgm_ws* ws, int* info_host, int batch);
+
+/*
  * The reference's other exact-GP models (pgmuvi/gps.py:915-1342: QuasiPeriodicGPModel, MaternGPModel,
  * PeriodicPlusStochasticGPModel, SeparableGPModel, ...) compose GPyTorch's stationary kernels with ScaleKernel /
  * ProductKernel / AdditiveKernel; `covar_module(x)` + `mll(output, y)` + `loss.backward()` (pgmuvi/trainers.py:179-181) of

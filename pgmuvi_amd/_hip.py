@@ -25,6 +25,7 @@ SYMBOLS = {
     "pgm_workspace_create": (c_int, [POINTER(c_void_p), c_int, c_int64, c_int, c_int, c_int]),
     "pgm_workspace_destroy": (c_int, [c_void_p]),
     "pgm_workspace_bytes": (c_size_t, [c_void_p]),
+    "pgm_factorisation_status": (c_int, [c_void_p, c_void_p, c_int]),
     "pgm_sm_kernel_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "pgm_mll_value_grad_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int,
@@ -143,6 +144,16 @@ class Workspace:
             self.close()
         except Exception:
             pass
+
+    def factorisation_failed(self, batch: int = 1):
+        """Did any of the ``batch`` problems of the last evaluation on this workspace fail to factor?  Waits for the event the
+        library records after the factorisation sweep only -- the inverse/gradient pass keeps running behind it -- so the caller's
+        host work overlaps the rest of the evaluation (pgm_factorisation_status).  None when nothing was published (the
+        evaluation ran inside a stream capture): the caller then reads ``info`` from the device."""
+        rc = load().pgm_factorisation_status(self.handle, None, int(batch))
+        if rc < 0:
+            return None
+        return rc > 0
 
     # -- profiling ---------------------------------------------------------
     def profile(self, on: bool):

@@ -92,7 +92,12 @@ struct pgm_ws {
   // hipGraph replay of the launch sequence between k_precompute and k_stage_out
   bool use_graph;
   hipStream_t cap_stream;
-  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; hipGraphExec_t exec; };
+  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; int parts; hipGraphExec_t exec; };
+  // factorisation status for the host, final as soon as the sweep is (pgm_factorisation_status)
+  hipEvent_t ev_status;  // recorded between the two parts of an evaluation
+  int* info_host;        // host-mapped pinned copy of `info`, written by k_publish_info at the end of the sweep
+  int* info_host_dev;    // its device address
+  int status_batch;      // problems of the last evaluation that published a status (0: none, or inside a caller's capture)
   std::vector<GraphEntry> graphs;
   // profiling
   bool prof_on;

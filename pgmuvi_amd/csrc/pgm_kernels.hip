@@ -1188,6 +1188,11 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   }
 }
 
+// the factorisation status of every problem of the call, copied to host-mapped memory at the end of the sweep
+__global__ __launch_bounds__(256) void k_publish_info(PgmDev P, int* __restrict__ host_mapped) {
+  for (int b = threadIdx.x; b < P.batch; b += 256) host_mapped[b] = P.info[b];
+}
+
 // ---------------------------------------------------------------------------
 // Results leave the workspace for the caller's arrays.  Together with k_precompute this is the
 // only kernel that sees caller pointers: everything in between works on workspace addresses

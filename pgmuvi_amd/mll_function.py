@@ -17,14 +17,24 @@ from .gpytorch import settings
 from .gpytorch.utils.errors import NanError, NotPSDError, NumericalWarning
 
 
+def _failed(out) -> bool:
+    """Did a factorisation of this evaluation fail?  The one host synchronisation of ``mll(output, y)`` (GPyTorch's
+    ``psd_safe_cholesky`` has the same one): it waits for the end of the factorisation sweep only, not for the inverse /
+    gradient pass behind it, so the Python work between ``mll(...)`` and ``loss.cpu()`` -- backward, optimiser step --
+    overlaps the rest of the evaluation."""
+    ws = out.get("workspace")
+    info = out["info"]
+    status = ws.factorisation_failed(info.numel()) if hasattr(ws, "factorisation_failed") else None
+    return bool((info != 0).any()) if status is None else status
+
+
 def _evaluate(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, need_grad):
     """Runs the HIP evaluation with GPyTorch's psd_safe_cholesky retry policy:
     jitter 0 first, then cholesky_jitter * 10**i for i < cholesky_max_tries."""
     out = _hip.mll_value_grad(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, 0.0, need_grad)
     if settings.check_cholesky_info.off():
         return out, 0.0
-    info = out["info"]
-    if not bool((info != 0).any()):
+    if not _failed(out):
         return out, 0.0
     if bool(torch.isnan(y).any()) or bool(torch.isnan(w).any()):
         raise NanError("cholesky: NaN in the inputs of the marginal log likelihood.")
@@ -34,7 +44,7 @@ def _evaluate(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, need_gra
         jitter = base * (10 ** i)
         warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
         out = _hip.mll_value_grad(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, jitter, need_grad)
-        if not bool((out["info"] != 0).any()):
+        if not _failed(out):
             return out, jitter
     raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
 
@@ -111,7 +121,7 @@ def _evaluate_dense(A, r, need_grad):
 def _evaluate_kernel(x, y, mean, noise_vec, noise_scalar, program, theta, need_grad):
     """The fused generic-kernel evaluation with the same jitter-retry policy as ``_evaluate``."""
     out = _hip.mll_kernel_value_grad(x, y, mean, noise_vec, noise_scalar, program, theta, 0.0, need_grad)
-    if settings.check_cholesky_info.off() or not bool(out["info"] != 0):
+    if settings.check_cholesky_info.off() or not _failed(out):
         return out, 0.0
     if bool(torch.isnan(y).any()) or bool(torch.isnan(theta).any()):
         raise NanError("cholesky: NaN in the inputs of the marginal log likelihood.")
@@ -121,7 +131,7 @@ def _evaluate_kernel(x, y, mean, noise_vec, noise_scalar, program, theta, need_g
         jitter = base * (10 ** i)
         warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
         out = _hip.mll_kernel_value_grad(x, y, mean, noise_vec, noise_scalar, program, theta, jitter, need_grad)
-        if not bool(out["info"] != 0):
+        if not _failed(out):
             return out, jitter
     raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
 

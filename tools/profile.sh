@@ -12,6 +12,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $d -o stats -- tools/eva
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d -o fetch -- tools/evalloop "$@" > $d/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d -o write -- tools/evalloop "$@" > $d/write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $d -o tcc -- tools/evalloop "$@" > $d/tcc.log 2>&1
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $d -o mfma -- tools/evalloop "$@" > $d/mfma.log 2>&1
+m=$(find $d -name 'mfma_counter_collection.csv' | head -1)
+python3 tools/pmc_counter.py "$m" MfmaUtil > $d/mfma_util.json
 f=$(find $d -name 'fetch_counter_collection.csv' | head -1); w=$(find $d -name 'write_counter_collection.csv' | head -1); t=$(find $d -name 'tcc_counter_collection.csv' | head -1)
 python3 tools/pmc_traffic.py "$f" "$w" $t > $d/traffic.json
 s=$(find $d -name 'stats_kernel_stats.csv' | head -1)
