@@ -123,14 +123,23 @@ def lib_sha16():
     return hashlib.sha256(open(_hip.lib_path(), "rb").read()).hexdigest()[:16]
 
 
-def measured_traffic(fused):
+def _pmc_workload(pmc):
+    """(n, light curves per launch) of the ``tools/evalloop n reps need_grad [q [batch]]`` run a traffic file was measured on."""
+    a = str(pmc.get("_workload", "")).split()[1:]
+    try:
+        return int(a[0]), (int(a[4]) if len(a) > 4 else 1)
+    except (IndexError, ValueError):
+        return None
+
+
+def measured_traffic(fused, n, nloc):
     """Memory-side bytes per sweep launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate
     runs, FETCH x2 for gfx950; tools/pmc_traffic.py) -- quoted only when that file was measured on the library that is
     running now (the file records the library's sha256); a stale file gives ``None``."""
     sha = lib_sha16()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB)), reverse=True):
         pmc = json.load(open(path))
-        if pmc.get("_lib_sha16") != sha:
+        if pmc.get("_lib_sha16") != sha or _pmc_workload(pmc) != (n, nloc):
             continue
         rows = [v for k, v in pmc.items() if isinstance(v, dict) and
                 (k.startswith("k_update") or (fused and (k.startswith("k_diag") or k.startswith("k_trsm"))))]
@@ -139,7 +148,7 @@ def measured_traffic(fused):
             return (sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in rows) / tot,
                     f"profiles/{os.path.basename(path)} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, same workload, "
                     f"same library sha256 {sha})")
-    return None, f"no profiles/{PMC_GLOB} measured on this library (sha256 {sha}): see tools/pmc_traffic.py"
+    return None, f"no profiles/{PMC_GLOB} measured on this library (sha256 {sha}) for N={n} x {nloc}: see tools/profile.sh"
 
 
 def sweep_roofline(prof, ws, n, nloc, steps):
@@ -164,7 +173,7 @@ def sweep_roofline(prof, ws, n, nloc, steps):
         upd_ms += fused_ms + diag_ms + trsm_ms
         upd_launches += fused_launches + diag_launches + trsm_launches
     achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-    traffic, traffic_src = measured_traffic(bool(fused_launches)) if (n == 4096 and nloc == 1) else (None, None)
+    traffic, traffic_src = measured_traffic(bool(fused_launches), n, nloc)
     kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles incl. early inverse-pass products; k_trsm: row solve + update tiles; "
              "k_update_rows): trailing-update + row-solve tile GEMM"
              if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN"
