@@ -73,9 +73,11 @@ __device__ __forceinline__ int acc_col(const WavePos& p, int tj) { return p.n0 +
 
 // ptrs(kb, pa, lda, pb, ldb): operand tile pointers of k-block kb: A tile is
 // NB x BM at pa (row pitch lda), B tile NB x BN at pb.
+// bsplit != 0: the right half of the B tile (columns BN/2..BN-1) sits bsplit columns further along in memory (two
+// separate column slabs multiplied as one operand).
 template <class C, class PtrFn>
 __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn&& ptrs,
-                                        v4d (&acc)[C::TM][C::TN]) {
+                                        v4d (&acc)[C::TM][C::TN], int bsplit = 0) {
   const int t = threadIdx.x;
   const WavePos wp = wave_pos<C>();
   constexpr int KC = C::KC;
@@ -95,7 +97,7 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
 #pragma unroll
     for (int s = 0; s < C::VB; ++s) {
       const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
-      if (C::EB >= C::NT || e < C::EB) xb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2);
+      if (C::EB >= C::NT || e < C::EB) xb[s] = *reinterpret_cast<const v2d*>(pb + (int64_t)(kr + row) * ldb + 2 * c2 + (2 * c2 >= C::BN / 2 ? bsplit : 0));
     }
   };
   auto sstore = [&](int buf, const v2d (&xa)[C::VA], const v2d (&xb)[C::VB]) {

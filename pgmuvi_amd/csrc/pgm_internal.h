@@ -7,6 +7,7 @@
 
 constexpr int PGM_MAX_QD = 16;      // Q*d the LDS staging is sized for
 constexpr int PGM_MAX_D = 2;
+constexpr int CRIT_MAX = 48;      // light curves per call the fused sweep is ever used for (batch x block rows <= 128, >= 3 block rows)
 
 // A composed stationary kernel as a sum of products of leaf kernels (pgm_generic.inc); mirrors pgm_kernel_program of the
 // C ABI.  Travels by value inside PgmDev (kernel arguments: decoding it touches no memory).
@@ -30,6 +31,7 @@ struct PgmDev {
   int64_t sA, sDinv, sPre, sVec, sPart, sLogdet, sDpart, sOut;
   double* A;          // [batch][np*np]  upper blocks: K+noise -> U ; strictly lower blocks: V = U^-T
   double* Dinv;       // [batch][nb][2][NB*NB]  0: Uinv_kk ([p][m])   1: Uinv_kk^T = V_kk ([k][n])
+  double* crit;       // [min(batch, CRIT_MAX)][NB*NB]  look-ahead of the fused sweep: copy of tile (k, k+1) before its row solve
   double* pre;        // [batch][3*qd + d][np]  cos, sin, x*v per (q,d); raw x per d
   double* r;          // [batch][np]  residual y - mean, consumed by the forward substitution
   double* z;          // [batch][np]  U^-T r
@@ -78,6 +80,9 @@ struct pgm_ws {
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
+  int lookahead;         // fused sweep: first block row whose successor's diagonal tile is formed inside the row-solve launch
+                         //   (no head launch on the chain from there on); >= 64: never
+  double* crit;          // (inside the Dinv allocation)
   int bh, bt;            // fused sweep: update-tile budgets of the head and row-solve launches (128x128 tiles)
   int window;            // big single light curves: rows per window of the windowed fused sweep (0 = plain panels)
   // early inverse pass (fused sweep, one light curve): the late diagonal-block launches have fewer update tiles than

@@ -462,8 +462,12 @@ static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit
 // The plan travels as two bit masks over the block rows (kernel arguments = scalar registers: decoding the
 // tile index must not touch memory): skip bit set = the row sits the launch out, two bit set = it applies
 // sources k_end-2 and k_end-1, else k_end-1 only.
+// Look-ahead (run_sweep): `own` >= 0 names the block row whose diagonal block is being factored by this very launch (its
+// other tiles take their last sources here, the (own, own) tile is left out) -- the tile next to the diagonal, (own, own+1),
+// is also copied to P.crit, where the following row-solve launch's diagonal-tile workgroups read it while the row solve
+// overwrites it in place; own_zero: the row has nothing pending, only that copy is made.
 constexpr int FILL_MAX_NB = 48;
-struct FillPlan { unsigned long long skip, two; };
+struct FillPlan { unsigned long long skip, two; int own, own_zero; };
 
 // One planned trailing-update tile (or BM x BN sub-tile of it): workgroup index widx counts the sub-tiles of
 // the planned rows >= r_from in row order.  Used by the filler workgroups of k_diag (128x128, 16 wavefronts)
@@ -479,16 +483,18 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
   const int si = sub / SUBN, sj = sub % SUBN;
   int r = r_from;
   for (; r < P.nb; ++r) {
-    const int cnt = ((plan.skip >> r) & 1ull) ? 0 : (P.nb - r) + nR;
+    const int cnt = ((plan.skip >> r) & 1ull) ? 0 : (r == plan.own ? (plan.own_zero ? 1 : (P.nb - r - 1) + nR) : (P.nb - r) + nR);
     if (tile < cnt) break;
     tile -= cnt;
   }
   if (r >= P.nb) return;                                     // (uniform for the workgroup)
   r = __builtin_amdgcn_readfirstlane(r);
   tile = __builtin_amdgcn_readfirstlane(tile);
-  const int lo = k_end - 1 - (int)((plan.two >> r) & 1ull);
-  const bool syrk = tile < P.nb - r;
-  const int j = syrk ? r + tile : tile - (P.nb - r);
+  const int own = (r == plan.own) ? 1 : 0;
+  const bool copy_only = own && plan.own_zero;
+  const int lo = copy_only ? k_end : k_end - 1 - (int)((plan.two >> r) & 1ull);
+  const bool syrk = tile < P.nb - r - own;
+  const int j = syrk ? r + own + tile : tile - (P.nb - r - own);
   const int pstart = (!syrk && j > lo) ? j : lo;             // V_pj vanishes for p < j
   const bool assign = !syrk && j >= lo;                      // first contribution to this tile of R
   double* A = P.A + b * P.sA;
@@ -509,12 +515,14 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
     gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
       pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
     }, acc);
-  } else {                                                   // two sources (the host never plans more)
+  } else if (nkb == 2) {                                     // two sources (the host never plans more)
     gemm_tn<C>(lds, 2, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
       pa = kb ? pa1 : pa0; lda = ld; pb = kb ? pb1 : pb0; ldb = kb ? ld : ldb0;
     }, acc);
   }
-  acc_store<C>(Cp, ld, acc, -1.0);
+  if (!copy_only) acc_store<C>(Cp, ld, acc, -1.0);
+  if (own && syrk && tile == 0)                              // (uniform) the tile the coming row solve's look-ahead reads
+    acc_store<C>(P.crit + (int64_t)b * NB * NB + (int64_t)si * C::BM * NB + sj * C::BN, NB, acc, -1.0);
 }
 
 // Second filler role of the late diagonal-block launches (one light curve): when the plan leaves CUs without an update
@@ -773,18 +781,72 @@ __device__ __forceinline__ void trsm_slab(const PgmDev& P, double* lds, double* 
   }
 }
 
-// workgroups >= nslabs of the grid are planned trailing-update tiles riding on this launch's idle CUs
-__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan) {
+// Look-ahead of the fused sweep: the diagonal tile of the NEXT block row, A_{k+1,k+1} -= U_{k,k+1}^T U_{k,k+1}, inside the row
+// solve's own launch, so that diagonal block k+1 can start right behind it (the rest of row k+1 takes source k beside that
+// diagonal block, as filler tiles).  No workgroup of the launch may wait for another, so each of the 36 workgroups -- one per
+// pair (s1 <= s2) of 16-column slabs -- solves its two slabs of U_{k,k+1} again for itself from the copy of the unsolved
+// tile in P.crit (the row solve proper overwrites the tile in place meanwhile), keeps them in LDS and multiplies the 16x16
+// block (s1, s2): the k range is dealt over the 8 wavefronts, partial blocks summed in fixed order.
+constexpr int LOOK_SLAB = 16, LOOK_NS = NB / LOOK_SLAB, LOOK_PAIRS = LOOK_NS * (LOOK_NS + 1) / 2;
+template <class C>
+__device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds, double* red2, int b, int k, int pair) {
+  static_assert(C::BM == NB && C::BN == 2 * LOOK_SLAB && C::TN == 1 && C::NT == 512, "two 16-column slabs per workgroup");
+  int s1, s2;
+  tri_decode(pair, s1, s2);
+  const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+  const double* Bp = P.crit + (int64_t)b * NB * NB + s1 * LOOK_SLAB;
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = Uinv; lda = NB; pb = Bp; ldb = NB;
+  }, acc, (s2 - s1) * LOOK_SLAB - LOOK_SLAB);
+  // (gemm_tn ends on a barrier: the staging area is free) the two solved slabs as one [k][32] image
+  constexpr int PX = 2 * LOOK_SLAB + 16;
+  const WavePos wp = wave_pos<C>();
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds[acc_row<C>(wp, ti, r) * PX + acc_col<C>(wp, 0)] = acc[ti][0][r];
+  __syncthreads();
+  v4d d = {0.0, 0.0, 0.0, 0.0};
+  constexpr int KPW = NB / 4 / (C::NT / 64);                 // MFMA k-steps per wavefront
+#pragma unroll
+  for (int kk = 0; kk < KPW; ++kk) {
+    const int krow = (wp.wave * KPW + kk) * 4 + (wp.lane >> 4);
+    d = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[krow * PX + (wp.lane & 15)], lds[krow * PX + LOOK_SLAB + (wp.lane & 15)], d, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red2[wp.wave * 256 + r * 64 + wp.lane] = d[r];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < C::NT / 64; ++w) tot += red2[w * 256 + threadIdx.x];
+    double* Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + s1 * LOOK_SLAB + (lane >> 4) + 4 * r) * P.ld + (k + 1) * NB + s2 * LOOK_SLAB + (lane & 15);
+    *Cd -= tot;
+  }
+}
+
+// workgroups [nlook, nlook + nslabs) are the row solve; the first nlook (0 or 36) form the next diagonal tile (look-ahead);
+// workgroups beyond are planned trailing-update tiles riding on this launch's idle CUs
+__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan, int nlook) {
   using C = CfgTrsmChain;
   __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
-  if ((int)blockIdx.x >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, (int)blockIdx.x - nslabs); return; }
-  int b = blockIdx.z, bx = blockIdx.x;
+  __shared__ double zs[NB];
+  __shared__ double red[C::NT / 64][C::WN];
+  if ((int)blockIdx.x < nlook) {
+    __shared__ double red2[(C::NT / 64) * 256];
+    lookahead_diag_tile<C>(P, lds, red2, blockIdx.z, k, (int)blockIdx.x);
+    return;
+  }
+  const int bx0 = (int)blockIdx.x - nlook;
+  if (bx0 >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, bx0 - nslabs); return; }
+  int b = blockIdx.z, bx = bx0;
   if ((int)gridDim.x == nslabs) xcd_batch_remap(bx, b);          // (no planned tiles in the grid: batches, panel sweep)
   const int slab = bx & 3;
   int jb = bx >> 2;
   if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
-  __shared__ double zs[NB];
-  __shared__ double red[C::NT / 64][C::WN];
   trsm_slab<C>(P, lds, zs, red, b, k, jb, slab);
 }
 

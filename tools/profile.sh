@@ -19,6 +19,8 @@ f=$(find $d -name 'fetch_counter_collection.csv' | head -1); w=$(find $d -name '
 python3 tools/pmc_traffic.py "$f" "$w" $t > $d/traffic.json
 s=$(find $d -name 'stats_kernel_stats.csv' | head -1)
 cp "$s" $d/kernel_stats.csv
+k=$(find $d -name 'stats_kernel_trace.csv' | head -1)
+python3 tools/timeline.py "$k" > $d/timeline.txt
 # keep the merge-back small: the raw per-dispatch tables go
 find $d -name '*_counter_collection.csv' -delete; find $d -name '*_kernel_trace.csv' -delete
 tail -2 $d/stats.log

@@ -1,18 +1,34 @@
 #!/usr/bin/env python3
-"""Per-launch timeline of the last evaluation in a rocprofv3 kernel-trace csv: tools/timeline.py <trace.csv>"""
-import csv, re, sys
+"""tools/timeline.py <kernel_trace.csv> [evals]  -- the launch sequence of the LAST evaluation in a rocprofv3 --kernel-trace
+csv: per block row the duration of the head / diagonal-block / row-solve launches and the gaps between them (us)."""
+import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_build' in r['Kernel_Name']]
-seq = rows[idx[-1]:]
-t0 = int(seq[0]['Start_Timestamp'])
-tot = {}
-for r in seq:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    m = re.search(r'k_\w+', r['Kernel_Name']); nm = m.group(0) if m else r['Kernel_Name'][:14]
-    tot.setdefault(nm, [0, 0.0]); tot[nm][0] += 1; tot[nm][1] += (e - s) / 1e3
-    if len(sys.argv) > 2:
-        print(f"{(s-t0)/1e3:9.1f} {nm:14s} {(e-s)/1e3:7.1f} wg {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}")
-print("span", (int(seq[-1]['End_Timestamp']) - t0) / 1e3, "us")
-for k, v in tot.items():
-    print(f"  {k:14s} n={v[0]:3d} total {v[1]:8.1f} us")
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]
+# last evaluation: from the last k_build (or k_dense_in) on
+start = max(i for i, n in enumerate(names) if "k_build" in n or "k_dense_in" in n)
+ev = rows[start:]
+t0 = int(ev[0]["Start_Timestamp"])
+def short(n):
+    for key in ("k_diag", "k_trsm", "k_update_rows", "k_update", "k_lauum", "k_build", "k_finalize", "k_publish", "k_stage", "k_precompute", "k_ainv"):
+        if key in n: return key
+    return n[:20]
+step = -1
+line = {}
+out = []
+prev_end = None
+tot_gap = 0.0
+for r in ev:
+    n = short(r["Kernel_Name"]); s = (int(r["Start_Timestamp"]) - t0) / 1e3; e = (int(r["End_Timestamp"]) - t0) / 1e3
+    gap = (s - prev_end) if prev_end is not None else 0.0
+    prev_end = e
+    tot_gap += gap
+    if n == "k_diag":
+        step += 1
+    out.append((step, n, s, e - s, gap, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", ""))))
+print(f"# last evaluation: {len(ev)} launches, {prev_end:.1f} us from first start to last end, {tot_gap:.1f} us of gaps")
+print("# step kernel            start_us   dur_us  gap_us  workgroups")
+for st, n, s, d, g, gx, wx in out:
+    try: wgs = int(gx) // max(int(wx), 1)
+    except Exception: wgs = gx
+    print(f"{st:4d} {n:16s} {s:9.1f} {d:8.2f} {g:6.2f}  {wgs}")
