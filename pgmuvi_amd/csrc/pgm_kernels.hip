@@ -441,7 +441,7 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
 // workgroup is the same 16 wavefronts as the factoring one and multiplies one 128x128 tile at a
 // time, a 32x32 sub-tile per wavefront.
 #ifndef PGM_FILL_PF
-#define PGM_FILL_PF 1            // deeper register prefetch (2, 4) measured: no change, the filler loop is not latency-bound
+#define PGM_FILL_PF 2            // two chunks in flight: a 256-deep filler tile 49.6 -> 45.2 us, a 128-deep one 29.4 -> 27.3 (tools/tileprobe)
 #endif
 #ifndef PGM_FILL_KB
 #define PGM_FILL_KB 16
@@ -786,10 +786,10 @@ __device__ __forceinline__ void trsm_slab(const PgmDev& P, double* lds, double* 
 // diagonal block, as filler tiles).  No workgroup of the launch may wait for another, so each of the 36 workgroups -- one per
 // pair (s1 <= s2) of 16-column slabs -- solves its two slabs of U_{k,k+1} again for itself from the copy of the unsolved
 // tile in P.crit (the row solve proper overwrites the tile in place meanwhile), keeps them in LDS and multiplies the 16x16
-// block (s1, s2): the k range is dealt over the 8 wavefronts, partial blocks summed in fixed order.
+// block (s1, s2).
 constexpr int LOOK_SLAB = 16, LOOK_NS = NB / LOOK_SLAB, LOOK_PAIRS = LOOK_NS * (LOOK_NS + 1) / 2;
 template <class C>
-__device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds, double* red2, int b, int k, int pair) {
+__device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds, int b, int k, int pair) {
   static_assert(C::BM == NB && C::BN == 2 * LOOK_SLAB && C::TN == 1 && C::NT == 512, "two 16-column slabs per workgroup");
   int s1, s2;
   tri_decode(pair, s1, s2);
@@ -808,23 +808,21 @@ __device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds
 #pragma unroll
     for (int r = 0; r < 4; ++r) lds[acc_row<C>(wp, ti, r) * PX + acc_col<C>(wp, 0)] = acc[ti][0][r];
   __syncthreads();
-  v4d d = {0.0, 0.0, 0.0, 0.0};
-  constexpr int KPW = NB / 4 / (C::NT / 64);                 // MFMA k-steps per wavefront
+  // one wavefront, the 32 k-steps in order, starting from -C: the very sequence of operations a trailing-update tile
+  // applies to this block (acc_load_neg, MFMAs with k ascending, store of -acc), so the factor -- and with it the value --
+  // is bit for bit what the schedules without look-ahead produce
+  if (wp.wave == 0) {
+    double* Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + s1 * LOOK_SLAB + (wp.lane >> 4)) * P.ld + (k + 1) * NB + s2 * LOOK_SLAB + (wp.lane & 15);
+    v4d d;
 #pragma unroll
-  for (int kk = 0; kk < KPW; ++kk) {
-    const int krow = (wp.wave * KPW + kk) * 4 + (wp.lane >> 4);
-    d = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[krow * PX + (wp.lane & 15)], lds[krow * PX + LOOK_SLAB + (wp.lane & 15)], d, 0, 0, 0);
-  }
+    for (int r = 0; r < 4; ++r) d[r] = -Cd[(int64_t)4 * r * P.ld];
+#pragma unroll 8
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const int krow = kk * 4 + (wp.lane >> 4);
+      d = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[krow * PX + (wp.lane & 15)], lds[krow * PX + LOOK_SLAB + (wp.lane & 15)], d, 0, 0, 0);
+    }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red2[wp.wave * 256 + r * 64 + wp.lane] = d[r];
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double tot = 0.0;
-#pragma unroll
-    for (int w = 0; w < C::NT / 64; ++w) tot += red2[w * 256 + threadIdx.x];
-    double* Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + s1 * LOOK_SLAB + (lane >> 4) + 4 * r) * P.ld + (k + 1) * NB + s2 * LOOK_SLAB + (lane & 15);
-    *Cd -= tot;
+    for (int r = 0; r < 4; ++r) Cd[(int64_t)4 * r * P.ld] = -d[r];
   }
 }
 
@@ -835,11 +833,7 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
   __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
   __shared__ double zs[NB];
   __shared__ double red[C::NT / 64][C::WN];
-  if ((int)blockIdx.x < nlook) {
-    __shared__ double red2[(C::NT / 64) * 256];
-    lookahead_diag_tile<C>(P, lds, red2, blockIdx.z, k, (int)blockIdx.x);
-    return;
-  }
+  if ((int)blockIdx.x < nlook) { lookahead_diag_tile<C>(P, lds, blockIdx.z, k, (int)blockIdx.x); return; }
   const int bx0 = (int)blockIdx.x - nlook;
   if (bx0 >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, bx0 - nslabs); return; }
   int b = blockIdx.z, bx = bx0;
@@ -1442,6 +1436,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_probe(const double* A, int64_t 
 #pragma unroll
     for (int tj = 0; tj < C::TN; ++tj) s += acc[ti][tj][0] + acc[ti][tj][3];
   if (s == 1.2345) out[0] = s;
+}
+
+// Tile-product probe (tools only): workgroup t does what a trailing-update tile does -- reads its C tile, multiplies `nkb`
+// k-blocks of two operand panels, writes the tile back -- on a synthetic 24-column arrangement of distinct tiles.
+template <class C, int WPS>
+__global__ __launch_bounds__(C::NT, WPS) void k_tile_probe(double* A, int64_t ld, int nkb) {
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  constexpr int SUBM = NB / C::BM, SUBN = NB / C::BN;
+  const int sub = blockIdx.x % (SUBM * SUBN), t = blockIdx.x / (SUBM * SUBN);
+  const int r = 8 + t / 24, j = t % 24, si = sub / SUBN, sj = sub % SUBN;
+  double* Cp = A + ((int64_t)r * NB + si * C::BM) * ld + j * NB + sj * C::BN;
+  v4d acc[C::TM][C::TN];
+  acc_load_neg<C>(Cp, ld, acc);
+  const double* pa0 = A + (int64_t)(r - 8) * NB + si * C::BM;
+  const double* pb0 = A + (int64_t)j * NB + sj * C::BN;
+  gemm_tn<C>(lds, nkb, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+    pa = pa0 + (int64_t)kb * NB * ld; lda = ld; pb = pb0 + (int64_t)kb * NB * ld; ldb = ld;
+  }, acc);
+  acc_store<C>(Cp, ld, acc, -1.0);
 }
 
 // ---------------------------------------------------------------------------

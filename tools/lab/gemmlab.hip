@@ -1,0 +1,122 @@
+// tools/lab/gemmlab.hip -- where the tile GEMM loop loses its cycles: the loop of pgm_gemm.h with parts switched off.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -I../../pgmuvi_amd/csrc -o gemmlab gemmlab.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "pgm_gemm.h"
+
+template <class C, bool GLOAD, bool SSTORE, bool BARRIER>
+__device__ __forceinline__ void gemm_lab(double* __restrict__ lds, int nkb, const double* pa0, const double* pb0, int64_t ld, v4d (&acc)[C::TM][C::TN]) {
+  const int t = threadIdx.x;
+  const WavePos wp = wave_pos<C>();
+  constexpr int KC = C::KC;
+  const int nchunks = nkb * (NB / KC);
+  constexpr int D = C::PF;
+  v2d ra[D][C::VA], rb[D][C::VB];
+  auto gload = [&](int c, v2d (&xa)[C::VA], v2d (&xb)[C::VB]) {
+    const int kr = c * KC;
+#pragma unroll
+    for (int s = 0; s < C::VA; ++s) { const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
+      xa[s] = *reinterpret_cast<const v2d*>(pa0 + (int64_t)(kr + row) * ld + 2 * c2); }
+#pragma unroll
+    for (int s = 0; s < C::VB; ++s) { const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
+      xb[s] = *reinterpret_cast<const v2d*>(pb0 + (int64_t)(kr + row) * ld + 2 * c2); }
+  };
+  auto sstore = [&](int buf, const v2d (&xa)[C::VA], const v2d (&xb)[C::VB]) {
+    double* As = lds + buf * C::STAGE; double* Bs = As + KC * C::PA;
+#pragma unroll
+    for (int s = 0; s < C::VA; ++s) { const int e = t + C::NT * s, row = e / (C::BM / 2), c2 = e % (C::BM / 2);
+      *reinterpret_cast<v2d*>(As + row * C::PA + 2 * c2) = xa[s]; }
+#pragma unroll
+    for (int s = 0; s < C::VB; ++s) { const int e = t + C::NT * s, row = e / (C::BN / 2), c2 = e % (C::BN / 2);
+      *reinterpret_cast<v2d*>(Bs + row * C::PB + 2 * c2) = xb[s]; }
+  };
+#pragma unroll
+  for (int u = 0; u < D; ++u) gload(u, ra[u], rb[u]);
+  sstore(0, ra[0], rb[0]);
+  sstore(1, ra[0], rb[0]);
+  __syncthreads();
+  for (int c0 = 0; c0 < nchunks; c0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int c = c0 + u;
+      if (GLOAD && c + D < nchunks) gload(c + D, ra[u], rb[u]);
+      const double* As = lds + (c & 1) * C::STAGE;
+      const double* Bs = As + KC * C::PA;
+#pragma unroll
+      for (int kk = 0; kk < KC / 4; ++kk) {
+        const int krow = kk * 4 + (wp.lane >> 4);
+        double a[C::TM], b[C::TN];
+#pragma unroll
+        for (int ti = 0; ti < C::TM; ++ti) a[ti] = As[krow * C::PA + wp.m0 + ti * 16 + (wp.lane & 15)];
+#pragma unroll
+        for (int tj = 0; tj < C::TN; ++tj) b[tj] = Bs[krow * C::PB + wp.n0 + tj * 16 + (wp.lane & 15)];
+#pragma unroll
+        for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      }
+      if (SSTORE && c + 1 < nchunks) sstore((c + 1) & 1, ra[(u + 1) % D], rb[(u + 1) % D]);
+      if (BARRIER) __syncthreads();
+    }
+  }
+}
+
+template <class C, int WPS, bool GLOAD, bool SSTORE, bool BARRIER>
+__global__ __launch_bounds__(C::NT, WPS) void k_lab(const double* A, int64_t ld, int nkb, double* out) {
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  const int64_t off = (int64_t)(blockIdx.x % 8) * 2 * C::BM;
+  gemm_lab<C, GLOAD, SSTORE, BARRIER>(lds, nkb, A + off, A + off + C::BM, ld, acc);
+  double s = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) s += acc[ti][tj][0] + acc[ti][tj][3];
+  if (s == 1.2345) out[0] = s;
+}
+
+template <class C, int WPS, bool G, bool S, bool B>
+void run(const char* name, const double* A, int64_t ld, double* out, int blocks, int nkb) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 6; ++rep) {
+    if (rep == 1) hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_lab<C, WPS, G, S, B>), dim3(blocks), dim3(C::NT), 0, 0, A, ld, nkb, out);
+  }
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  const double tf = 2.0 * C::BM * C::BN * NB * nkb * blocks / (ms * 1e-3) / 1e12;
+  printf("%-64s blocks %4d nkb %2d: %8.1f us  %6.2f TFLOP/s = %.3f of 78.6%s\n", name, blocks, nkb, ms * 1e3, tf, tf / 78.6, hipGetLastError() == hipSuccess ? "" : " FAILED");
+}
+
+int main() {
+  const int64_t ld = 4096;
+  double* A; double* out;
+  hipMalloc(&A, sizeof(double) * ld * 2048); hipMalloc(&out, 64);
+  std::vector<double> h((size_t)ld * 2048);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)((i * 2654435761u) % 1000);
+  hipMemcpy(A, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+  using Big = TileCfg<128, 128, 64, 64, 2>;
+  using Big1 = TileCfg<128, 128, 64, 64, 1>;
+  using W8 = TileCfg<128, 128, 64, 32, 2, 512>;
+  using F16 = TileCfg<128, 128, 32, 32, 2, 1024, 16>;
+  using Sm = TileCfg<64, 64, 32, 32, 4>;
+  for (int nkb : {4, 16}) {
+    run<Big, 2, true, true, true>("4 waves 64x64/wave PF2, 2 WG/CU: full loop", A, ld, out, 512, nkb);
+    run<Big, 2, false, true, true>("   no global loads", A, ld, out, 512, nkb);
+    run<Big, 2, false, false, true>("   no global loads, no LDS stores", A, ld, out, 512, nkb);
+    run<Big, 2, false, false, false>("   no global loads, no LDS stores, no barriers", A, ld, out, 512, nkb);
+    run<Big, 2, true, true, true>("   full loop, 1 WG/CU (256 blocks)", A, ld, out, 256, nkb);
+    run<Big, 2, false, false, false>("   bare MFMA + LDS reads, 1 WG/CU (256 blocks)", A, ld, out, 256, nkb);
+    run<Big1, 2, true, true, true>("4 waves 64x64/wave PF1, 2 WG/CU: full loop", A, ld, out, 512, nkb);
+    run<W8, 2, true, true, true>("8 waves 64x32/wave PF2, 1 WG/CU by regs: full loop", A, ld, out, 256, nkb);
+    run<W8, 2, false, false, false>("   bare MFMA + LDS reads", A, ld, out, 256, nkb);
+    run<F16, 4, true, true, true>("16 waves 32x32/wave PF2, 1 WG/CU: full loop", A, ld, out, 256, nkb);
+    run<F16, 4, false, false, true>("   no global loads, no LDS stores", A, ld, out, 256, nkb);
+    run<F16, 4, false, false, false>("   bare MFMA + LDS reads", A, ld, out, 256, nkb);
+    run<Sm, 4, true, true, true>("4 waves 32x32/wave (64x64 tile) PF4, 4 WG/CU: full loop", A, ld, out, 1024, nkb);
+    run<Sm, 4, false, false, false>("   bare MFMA + LDS reads", A, ld, out, 1024, nkb);
+  }
+  return 0;
+}
