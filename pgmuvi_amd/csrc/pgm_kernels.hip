@@ -731,9 +731,15 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
 using CfgTrsm = TileCfg<128, 32, 32, 32, 4>;               // (prediction right-hand sides)
 // 8 wavefronts, a 32x16 sub-tile each: the launch sits on the chain and is bound by its own latency, so the
 // multiply body is cut to 64 MFMAs per wavefront (2 us) rather than sized for operand reuse
-using CfgTrsmChain = TileCfg<128, 32, 32, 16, 4, 512>;
+#ifndef PGM_TRSM_BN
+#define PGM_TRSM_BN 32
+#endif
+using CfgTrsmChain = TileCfg<128, PGM_TRSM_BN, PGM_TRSM_BN == 32 ? 32 : 16, 16, 4, 512>;
+using CfgLook = TileCfg<128, 32, 32, 16, 4, 512>;          // the look-ahead workgroups: two 16-column slabs each
+constexpr int TRSM_SLABS = NB / CfgTrsmChain::BN;
 using CfgHead = TileCfg<64, 64, 32, 16, 4, 512>;           // the chain's update tiles: 64x64 sub-tiles, same reasoning
-constexpr int CHAIN_LDS = CfgTrsmChain::LDS_DOUBLES > CfgHead::LDS_DOUBLES ? CfgTrsmChain::LDS_DOUBLES : CfgHead::LDS_DOUBLES;
+constexpr int CHAIN_LDS = CfgLook::LDS_DOUBLES > CfgHead::LDS_DOUBLES ? CfgLook::LDS_DOUBLES : CfgHead::LDS_DOUBLES;
+static_assert(CfgTrsmChain::LDS_DOUBLES <= CHAIN_LDS, "row-solve staging");
 
 // planned trailing-update tiles as their own launch (the fused sweep's head update of block row k, plus
 // whatever else the host's plan puts on this launch's idle CUs)
@@ -833,13 +839,13 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
   __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
   __shared__ double zs[NB];
   __shared__ double red[C::NT / 64][C::WN];
-  if ((int)blockIdx.x < nlook) { lookahead_diag_tile<C>(P, lds, blockIdx.z, k, (int)blockIdx.x); return; }
+  if ((int)blockIdx.x < nlook) { lookahead_diag_tile<CfgLook>(P, lds, blockIdx.z, k, (int)blockIdx.x); return; }
   const int bx0 = (int)blockIdx.x - nlook;
   if (bx0 >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, bx0 - nslabs); return; }
   int b = blockIdx.z, bx = bx0;
   if ((int)gridDim.x == nslabs) xcd_batch_remap(bx, b);          // (no planned tiles in the grid: batches, panel sweep)
-  const int slab = bx & 3;
-  int jb = bx >> 2;
+  const int slab = bx % TRSM_SLABS;
+  int jb = bx / TRSM_SLABS;
   if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
   trsm_slab<C>(P, lds, zs, red, b, k, jb, slab);
 }

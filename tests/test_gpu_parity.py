@@ -1188,6 +1188,47 @@ def test_early_inverse_pass_equals_the_plain_schedule(dev, monkeypatch, case):
         assert _rel(outs["1"][f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
+@pytest.mark.parametrize("n,batch,need_grad", [(2900, 1, True), (1500, 3, True), (2900, 1, False), (640, 1, True)])
+def test_look_ahead_is_bit_for_bit_the_three_launch_chain(dev, monkeypatch, n, batch, need_grad):
+    """Fused sweep with look-ahead (the row-solve launch forms the next diagonal tile, the head launch leaves the chain;
+    PGM_LOOKAHEAD = first block row that does it, default 0) against the three-launch chain (PGM_LOOKAHEAD=99) and a switch in
+    mid-sweep: the look-ahead workgroups apply the very operation sequence of a trailing-update tile, so U, V, the value and the
+    residual gradients are identical bit for bit; the spectral-mixture gradients only differ by the split of the inverse pass
+    (the early products move with the schedule)."""
+    gen = torch.Generator().manual_seed(n + batch)
+    xs, ys, zs = [], [], []
+    for _ in range(batch):
+        xs.append(torch.sort(torch.rand(n, generator=gen, dtype=D) * 900)[0]); ys.append(torch.randn(n, generator=gen, dtype=D))
+        zs.append(0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D))
+    w = torch.tensor([0.6, 0.3, 0.2], dtype=D); mu = torch.tensor([[0.02], [0.11], [0.3]], dtype=D); v = torch.tensor([[0.003], [0.01], [0.02]], dtype=D)
+    outs = {}
+    for la in ("0", "99", "7"):
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_LOOKAHEAD", la)
+        if batch == 1:
+            o = _hip_eval(dev, xs[0], ys[0], 0.1, zs[0], w, mu, v, need_grad=need_grad)
+        else:
+            X, Y, Z = (torch.stack(a).to(dev) for a in (xs, ys, zs))
+            o = _hip.mll_value_grad(X.unsqueeze(-1), Y, torch.full_like(Y, 0.1), Z, None, w.to(dev).expand(batch, -1).contiguous(),
+                                    mu.to(dev).expand(batch, -1, -1).contiguous(), v.to(dev).expand(batch, -1, -1).contiguous(), 0, 0.0, need_grad)
+            torch.cuda.synchronize()
+        outs[la] = {k: t.clone().cpu() for k, t in o.items() if torch.is_tensor(t)}
+    monkeypatch.delenv("PGM_LOOKAHEAD")
+    _hip.release_workspaces()
+    for la in ("99", "7"):
+        assert torch.equal(outs["0"]["mll"], outs[la]["mll"]), la
+        assert torch.equal(outs["0"]["info"], outs[la]["info"])
+        if need_grad:
+            assert torch.equal(outs["0"]["g_mean"], outs[la]["g_mean"]), la
+            for p in ("w", "mu", "v", "noise"):
+                assert _rel(outs["0"][f"g_{p}"].reshape(-1), outs[la][f"g_{p}"].reshape(-1)) < 1e-11, (p, la)
+    val, gr = orc.mll_value_grad_closed_form(xs[0], ys[0], 0.1, zs[0], w, mu, v, 0, 0.0)
+    assert abs(float(outs["0"]["mll"].reshape(-1)[0]) - float(val)) < MLL_TOL
+    if need_grad:
+        for p in ("w", "mu", "v"):
+            assert _rel(outs["0"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
 def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatch):
     """34..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
     the diagonal-block launches), the rows beyond it get one deep update per window.  Same factor, hence the same value bit
