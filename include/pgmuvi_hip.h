@@ -17,6 +17,9 @@
  *    factorisation is NOT a return value (nothing synchronises): it is reported through the device-side
  *    `info` output of the evaluation calls, LAPACK style (0 ok, k > 0 = 1-based index of the first
  *    non-positive pivot), with NaN in the value and in every gradient output of that problem;
+ *  - a workspace belongs to the device it was created on: every call that takes one runs there whatever
+ *    the caller's current device is, and puts the caller's current device back before it returns (the
+ *    stream and the pointers must belong to the workspace's device);
  *  - no function throws or aborts; a workspace is not re-entrant (one caller
  *    thread per handle at a time).
  */

@@ -268,37 +268,40 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     mud = _dev64(mu.reshape(B, q, d), dev)
     vd = _dev64(v.reshape(B, q, d), dev)
     ws = workspace or get_workspace(dev, n, q, d, B)
-    out = dict(
-        mll=torch.empty(B, dtype=torch.float64, device=dev),
-        info=torch.zeros(B, dtype=torch.int32, device=dev),
-    )
-    if need_grad:
-        out.update(
-            g_w=torch.empty((B, q), dtype=torch.float64, device=dev),
-            g_mu=torch.empty((B, q, d), dtype=torch.float64, device=dev),
-            g_v=torch.empty((B, q, d), dtype=torch.float64, device=dev),
-            g_noise=torch.empty((B, n), dtype=torch.float64, device=dev),
-            g_mean=torch.empty((B, n), dtype=torch.float64, device=dev),
-        )
-    g = lambda k: _ptr(out.get(k))
+    # every fp64 output in ONE allocation (this runs once per training iteration between two device launches: each
+    # torch.empty / view costs microseconds of host time the GPU spends idle); `info` is written by every call
+    qd = q * d
+    sizes = (B, B * q, B * qd, B * qd, B * n, B * n) if need_grad else (B,)
+    buf = torch.empty(sum(sizes), dtype=torch.float64, device=dev)
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    base = buf.data_ptr()
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + sz)
+    ptr = lambda i: c_void_p(base + 8 * offs[i])
+    null = c_void_p(None)
     lib = load()
-    with torch.cuda.device(dev):
-        st = current_stream_ptr(dev)
-        # always the batched entry point (B = 1 when unbatched): the scalar noise then
-        # travels as a device pointer and no host synchronisation is needed
-        ns = None
-        if noise_scalar is not None:
-            ns = _dev64(torch.as_tensor(noise_scalar, device=dev).expand(B).reshape(B), dev)
-        rc = lib.pgm_mll_value_grad_batched_f64(
-            ws.handle, B, _ptr(xd), _ptr(yd), _ptr(md), _ptr(nz), _ptr(ns), n, d, _ptr(wd), _ptr(mud), _ptr(vd), q,
-            int(dim_order), float(jitter), 1 if need_grad else 0,
-            g("mll"), g("g_w"), g("g_mu"), g("g_v"), g("g_noise"), g("g_mean"), g("info"), st)
-        _check(rc, "pgm_mll_value_grad_batched_f64")
-        out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
-    if not batched:
-        for k in ("mll", "info", "g_w", "g_mu", "g_v", "g_noise", "g_mean"):
-            if k in out:
-                out[k] = out[k][0]
+    st = current_stream_ptr(dev)
+    # always the batched entry point (B = 1 when unbatched): the scalar noise then
+    # travels as a device pointer and no host synchronisation is needed
+    ns = None
+    if noise_scalar is not None:
+        ns = _dev64(torch.as_tensor(noise_scalar, device=dev).expand(B).reshape(B), dev)
+    rc = lib.pgm_mll_value_grad_batched_f64(
+        ws.handle, B, _ptr(xd), _ptr(yd), _ptr(md), _ptr(nz), _ptr(ns), n, d, _ptr(wd), _ptr(mud), _ptr(vd), q,
+        int(dim_order), float(jitter), 1 if need_grad else 0,
+        ptr(0), ptr(1) if need_grad else null, ptr(2) if need_grad else null, ptr(3) if need_grad else null,
+        ptr(4) if need_grad else null, ptr(5) if need_grad else null, _ptr(info), st)
+    _check(rc, "pgm_mll_value_grad_batched_f64")
+    lead = (B,) if batched else ()
+    out = dict(mll=buf[offs[0]:offs[1]].view(lead), info=info.view(lead))
+    if need_grad:
+        out["g_w"] = buf[offs[1]:offs[2]].view(lead + (q,))
+        out["g_mu"] = buf[offs[2]:offs[3]].view(lead + (q, d))
+        out["g_v"] = buf[offs[3]:offs[4]].view(lead + (q, d))
+        out["g_noise"] = buf[offs[4]:offs[5]].view(lead + (n,))
+        out["g_mean"] = buf[offs[5]:offs[6]].view(lead + (n,))
+    out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
     out["workspace"] = ws
     return out
 

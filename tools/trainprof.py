@@ -23,4 +23,6 @@ torch.cuda.synchronize(); print(f"n={n}: train() {(time.perf_counter()-t0)/iters
 pr = cProfile.Profile(); pr.enable()
 trainers.train(model=m, likelihood=lik, train_x=x, train_y=yy, maxiter=iters, miniter=iters, lr=1e-3, optim="AdamW", progress=False)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("tottime").print_stats("pgmuvi_amd", 30)
