@@ -289,14 +289,16 @@ __device__ __forceinline__ void lds_barrier() {
 // holds the 4 panel rows of its column, is factored with uniform multipliers
 // (v_readlane), and the rank-4 trailing update of both images is one MFMA each:
 //   acc -= P^T P  ==  mfma(-row, row, acc)   (the panel row IS the A and B fragment).
-__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane) {
+// `pre`: the sub-block's values already in registers (C layout) -- sub-block 0 comes straight from global memory, ahead of
+// the rest of the block's image.
+__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, const v4d* pre = nullptr) {
   const int g = lane >> 4, n = lane & 15;
   double* Mb = c.M + (s * DB) * PM + s * DB;
   double* pbuf = c.pbuf;                      // [4][32]
   v4d ua, va;                                 // A image, identity image (C layout)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    ua[r] = Mb[(g + 4 * r) * PM + n];
+    ua[r] = pre ? (*pre)[r] : Mb[(g + 4 * r) * PM + n];
     va[r] = (g + 4 * r == n) ? 1.0 : 0.0;
   }
   double fa[4], fb[4];
@@ -567,8 +569,8 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
-  if (t < NB / DB) {                                           // thread s builds the list of step s
-    const int s = t, ns = NB / DB;
+  if (t >= 64 && t < 64 + NB / DB) {                           // thread 64 + s builds the list of step s (not on the chain wave)
+    const int s = t - 64, ns = NB / DB;
     int cnt = 0;
     for (int i = s + 1; i < ns; ++i) {
       for (int j = 0; j <= s; ++j) blklist[s * BLK_MAX + cnt++] = (unsigned char)((i << 4) | j);
@@ -587,23 +589,6 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   c.Dinv1 = c.Dinv0 + NB * NB;
   c.info = P.info + b;
   c.kbase = k * NB;
-  // load the block (upper part is meaningful), clear the inverse images, fetch r_k
-  {  // all eight 16-B loads of a thread in flight at once (one memory round trip, not eight)
-    constexpr int NV = NB * NB / 2 / DIAG_THREADS;
-    v2d tmp[NV];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
-      tmp[u] = *reinterpret_cast<const v2d*>(c.Akk + (int64_t)row * P.ld + c2);
-    }
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
-      *reinterpret_cast<v2d*>(M + row * PM + c2) = tmp[u];
-    }
-  }   // (the zero triangles of the inverse images are cleared once, at workspace creation)
-  if (t < NB) { rsv[t] = P.r[b * P.sVec + k * NB + t]; alv[t] = 0.0; }
-  __syncthreads();
 #ifdef PGM_DIAG_STAMPS
   long long st_[40]; int sn_ = 0;
 #define STAMP() do { if (sn_ < 40) st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -611,8 +596,32 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
 #define STAMP() do {} while (0)
 #endif
   STAMP();
-  if (wave == 0) __builtin_amdgcn_s_setprio(3);              // the chain wave wins issue arbitration on its SIMD
-  if (wave == 0) diag_potrf16(c, 0, lane);
+  // load the block (upper part is meaningful), fetch r_k.  The chain wave asks for sub-block (0, 0) FIRST and factors it while
+  // the rest of the image is still arriving (loads return in order: its wait covers those four loads only); everybody else
+  // leaves that sub-block out of the image.  The barrier at the top of step 0 is where the image is complete.
+  {  // all eight 16-B loads of a thread in flight at once (one memory round trip, not eight)
+    constexpr int NV = NB * NB / 2 / DIAG_THREADS;
+    v4d first = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);                           // the chain wave wins issue arbitration on its SIMD
+#pragma unroll
+      for (int r = 0; r < 4; ++r) first[r] = c.Akk[(int64_t)((lane >> 4) + 4 * r) * P.ld + (lane & 15)];
+    }
+    v2d tmp[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+      tmp[u] = *reinterpret_cast<const v2d*>(c.Akk + (int64_t)row * P.ld + c2);
+    }
+    const double rk = (t < NB) ? P.r[b * P.sVec + k * NB + t] : 0.0;
+    if (wave == 0) diag_potrf16(c, 0, lane, &first);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+      if (row >= DB || c2 >= DB) *reinterpret_cast<v2d*>(M + row * PM + c2) = tmp[u];
+    }
+    if (t < NB) { rsv[t] = rk; alv[t] = 0.0; }
+  }   // (the zero triangles of the inverse images are cleared once, at workspace creation)
   STAMP();
   constexpr int NS = NB / DB;
   double lgsum = 0.0;          // (bookkeeping wave)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cmath>
+#include <algorithm>
 #include "pgm_gemm.h"
 
 template <class C, bool GLOAD, bool SSTORE, bool BARRIER>
@@ -77,6 +79,90 @@ __global__ __launch_bounds__(C::NT, WPS) void k_lab(const double* A, int64_t ld,
   if (s == 1.2345) out[0] = s;
 }
 
+
+// LDS-DMA staging: global_load_lds_dwordx4 writes each 1-KB operand row straight into its (padded) LDS row -- no staging
+// registers, no ds_write.  Two LDS buffers: the DMA of chunk c+1 is issued after the barrier that freed its buffer, runs
+// behind the MFMAs of chunk c and is waited for (vmcnt(0)) in front of the next barrier.
+template <class C>
+__device__ __forceinline__ void gemm_dma(double* __restrict__ lds, int nkb, const double* pa0, const double* pb0, int64_t ld, v4d (&acc)[C::TM][C::TN]) {
+  static_assert(C::BM == 128 && C::BN == 128, "one wave instruction per operand row");
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const WavePos wp = wave_pos<C>();
+  constexpr int KC = C::KC, NW = C::NT / 64, RPW = KC / NW;     // rows of each operand per wavefront and chunk
+  const int nchunks = nkb * (NB / KC);
+  typedef const double __attribute__((address_space(1)))* gptr;
+  typedef double __attribute__((address_space(3)))* lptr;
+  auto dma = [&](int c, int buf) {
+    double* As = lds + buf * C::STAGE; double* Bs = As + KC * C::PA;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int row = wave * RPW + r;
+      __builtin_amdgcn_global_load_lds((gptr)(pa0 + (int64_t)(c * KC + row) * ld + 2 * lane), (lptr)(As + row * C::PA), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(pb0 + (int64_t)(c * KC + row) * ld + 2 * lane), (lptr)(Bs + row * C::PB), 16, 0, 0);
+    }
+  };
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) dma(c + 1, (c + 1) & 1);
+    const double* As = lds + (c & 1) * C::STAGE;
+    const double* Bs = As + KC * C::PA;
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const int krow = kk * 4 + (wp.lane >> 4);
+      double a[C::TM], b[C::TN];
+#pragma unroll
+      for (int ti = 0; ti < C::TM; ++ti) a[ti] = As[krow * C::PA + wp.m0 + ti * 16 + (wp.lane & 15)];
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj) b[tj] = Bs[krow * C::PB + wp.n0 + tj * 16 + (wp.lane & 15)];
+#pragma unroll
+      for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+template <class C, int WPS>
+__global__ __launch_bounds__(C::NT, WPS) void k_lab_dma(const double* A, int64_t ld, int nkb, double* out) {
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  const int64_t off = (int64_t)(blockIdx.x % 8) * 2 * C::BM;
+  gemm_dma<C>(lds, nkb, A + off, A + off + C::BM, ld, acc);
+  double s = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) s += acc[ti][tj][0] + acc[ti][tj][3];
+  if (s == 1.2345) out[0] = s;
+  if (blockIdx.x == 0 && nkb == 1) out[8 + threadIdx.x] = acc[0][0][0] + acc[C::TM - 1][C::TN - 1][3];      // (check against the register-staged loop)
+}
+template <class C, int WPS>
+__global__ __launch_bounds__(C::NT, WPS) void k_lab_ref(const double* A, int64_t ld, int nkb, double* out) {
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  gemm_lab<C, true, true, true>(lds, nkb, A, A + C::BM, ld, acc);
+  if (blockIdx.x == 0) out[8 + threadIdx.x] = acc[0][0][0] + acc[C::TM - 1][C::TN - 1][3];
+}
+
+template <class C, int WPS>
+void run_dma(const char* name, const double* A, int64_t ld, double* out, int blocks, int nkb) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 6; ++rep) {
+    if (rep == 1) hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_lab_dma<C, WPS>), dim3(blocks), dim3(C::NT), 0, 0, A, ld, nkb, out);
+  }
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  const double tf = 2.0 * C::BM * C::BN * NB * nkb * blocks / (ms * 1e-3) / 1e12;
+  printf("%-64s blocks %4d nkb %2d: %8.1f us  %6.2f TFLOP/s = %.3f of 78.6%s\n", name, blocks, nkb, ms * 1e3, tf, tf / 78.6, hipGetLastError() == hipSuccess ? "" : " FAILED");
+}
+
 template <class C, int WPS, bool G, bool S, bool B>
 void run(const char* name, const double* A, int64_t ld, double* out, int blocks, int nkb) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -93,7 +179,7 @@ void run(const char* name, const double* A, int64_t ld, double* out, int blocks,
 int main() {
   const int64_t ld = 4096;
   double* A; double* out;
-  hipMalloc(&A, sizeof(double) * ld * 2048); hipMalloc(&out, 64);
+  hipMalloc(&A, sizeof(double) * ld * 2048); hipMalloc(&out, 8192);
   std::vector<double> h((size_t)ld * 2048);
   for (size_t i = 0; i < h.size(); ++i) h[i] = 1.0 + 1e-3 * (double)((i * 2654435761u) % 1000);
   hipMemcpy(A, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
@@ -102,7 +188,16 @@ int main() {
   using W8 = TileCfg<128, 128, 64, 32, 2, 512>;
   using F16 = TileCfg<128, 128, 32, 32, 2, 1024, 16>;
   using Sm = TileCfg<64, 64, 32, 32, 4>;
+  {  // the LDS-DMA loop computes what the register-staged loop computes
+    std::vector<double> r1(256), r2(256);
+    hipLaunchKernelGGL((k_lab_ref<Big, 2>), dim3(1), dim3(256), 0, 0, A, ld, 1, out); hipMemcpy(r1.data(), out + 8, 256 * 8, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL((k_lab_dma<Big, 2>), dim3(1), dim3(256), 0, 0, A, ld, 1, out); hipMemcpy(r2.data(), out + 8, 256 * 8, hipMemcpyDeviceToHost);
+    double md = 0; for (int i = 0; i < 256; ++i) md = std::max(md, std::abs(r1[i] - r2[i]));
+    printf("LDS-DMA loop vs register-staged loop: max |difference| %.3e (values ~%.3e)\n", md, r1[0]);
+  }
   for (int nkb : {4, 16}) {
+    run_dma<Big, 2>("4 waves 64x64/wave, LDS-DMA staging, 2 WG/CU", A, ld, out, 512, nkb);
+    run_dma<W8, 2>("8 waves 64x32/wave, LDS-DMA staging, 1 WG/CU by regs", A, ld, out, 256, nkb);
     run<Big, 2, true, true, true>("4 waves 64x64/wave PF2, 2 WG/CU: full loop", A, ld, out, 512, nkb);
     run<Big, 2, false, true, true>("   no global loads", A, ld, out, 512, nkb);
     run<Big, 2, false, false, true>("   no global loads, no LDS stores", A, ld, out, 512, nkb);
