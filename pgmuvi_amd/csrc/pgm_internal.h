@@ -49,6 +49,7 @@ struct PgmDev {
   double* out_gnoise; // [batch][np]
   double* out_gmean;  // [batch][np]
   int* info;          // [batch]
+  int* info_host;     // host-mapped copy of `info` (device address) that the LAST diagonal-block launch fills in, or null
   double jitter, noise_scalar;
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
   double *mll, *g_w, *g_mu, *g_v, *g_noise, *g_mean;
@@ -56,6 +57,7 @@ struct PgmDev {
   int ainv_from_tiles; // k-blocks per work item (0 = off): diag(A^-1) is taken from the accumulators of the (j, j) tiles' work items
                       //    in the inverse/gradient launch (item number s of the tile -> dpart row s) and the separate column-sum
                       //    pass over V is skipped
+  int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups)
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
   KProg prog;
 };
@@ -72,6 +74,7 @@ struct pgm_ws {
   int4* items;           // device copy of the work-item table
   std::vector<int4> items_host;
   int items_nb, items_batch, items_count, items_cap, items_kc;
+  int64_t part_rows;     // rows of `partials` per problem
   double items_epi, early_epi;  // epilogue weight the two work lists were split for (spectral mixture 3, generic kernels 15)
   // state of the last need_grad evaluation (for pgm_predict_f64)
   PgmDev last;
@@ -87,6 +90,7 @@ struct pgm_ws {
   int window;            // big single light curves: rows per window of the windowed fused sweep (0 = plain panels)
   // early inverse pass (fused sweep, one light curve): the late diagonal-block launches have fewer update tiles than
   // CUs; their spare workgroups form  R_ij = sum_p V_pi^T V_pj  over block rows p that are already final
+  int lauum_sub_max;     // inverse/gradient pass: quarter-tile workgroups when a call has at most this many work items in all (0: never)
   int early;             // 0 = off
   int early_nb;          // block rows the tables below were made for (-1: none)
   std::vector<int4> early_host;          // [final work items | filler tasks]
@@ -100,7 +104,7 @@ struct pgm_ws {
   struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; int parts; hipGraphExec_t exec; };
   // factorisation status for the host, final as soon as the sweep is (pgm_factorisation_status)
   hipEvent_t ev_status;  // recorded between the two parts of an evaluation
-  int* info_host;        // host-mapped pinned copy of `info`, written by k_publish_info at the end of the sweep
+  int* info_host;        // host-mapped pinned copy of `info`, written by the last diagonal-block launch of the sweep
   int* info_host_dev;    // its device address
   int status_batch;      // problems of the last evaluation that published a status (0: none, or inside a caller's capture)
   std::vector<GraphEntry> graphs;

@@ -694,6 +694,8 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
             P.logdet[b * P.sLogdet + k] = tot;
             // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
             if (firstbad >= 0 && *c.info == 0) *c.info = c.kbase + 1 + firstbad;
+            // the status is final with the last diagonal block: the host's copy (pgm_factorisation_status) is written here
+            if (k == P.nb - 1 && P.info_host) P.info_host[b] = *c.info;
           }
         }
       }
@@ -931,6 +933,7 @@ using CfgUpd = TileCfg<128, 128, 64, 32, PGM_UPD_PF, 512>;      // (experiment) 
 using CfgUpd = CfgBig;
 #endif
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
+using CfgSub = CfgSmall;                                     // quarter tiles of the inverse/gradient pass of short light curves
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
 constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);          // alpha slices, weights, wave partials
@@ -989,33 +992,38 @@ __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
   ainv_diag_item(P, (int)blockIdx.x, (int)blockIdx.y, red, (int)blockIdx.z);
 }
 
-template <int D, int ORDER>
+// C = CfgBig: one workgroup per work item, the whole 128x128 tile.  C = CfgSub (few work items: short light curves, where one
+// workgroup per tile would leave most CUs idle behind a 40 us gradient epilogue): four workgroups per work item, a 64x64
+// sub-tile each -- launch index 4 * item + sub-tile, one row of partial sums per workgroup (P.nitems counts workgroups).
+template <int D, int ORDER, class C>
 __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
-  using C = CfgBig;
+  constexpr int SUB = NB / C::BM;                              // sub-tiles per side (1 or 2)
+  static_assert(C::BM == C::BN && C::NT == NTHREADS && (SUB == 1 || SUB == 2), "whole tiles or quarter tiles");
   int b = blockIdx.z, bx = blockIdx.x;
   xcd_batch_remap(bx, b);
   if (P.info[b] != 0) return;
-  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double lds[CfgBig::LDS_DOUBLES];
   // the diag(A^-1) items ride at the end of the grid (placed first they delay the long inverse tiles: +0.04 ms)
   if (bx >= P.nitems) { const int a = bx - P.nitems; ainv_diag_item(P, a % P.nb, a / P.nb, lds, b); return; }
   // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
   // that no single workgroup sets the makespan; the contraction below is linear in the tile
   const int lb = bx;
-  const int4 item = P.items[lb];
+  const int4 item = P.items[lb / (SUB * SUB)];
   const int i = item.x, j = item.y, p0 = item.z, plen = item.w & 0xffff;
+  const int mo = ((lb % (SUB * SUB)) / SUB) * C::BM, no = ((lb % (SUB * SUB)) % SUB) * C::BN;      // the sub-tile's place in the tile
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
   v4d acc[C::TM][C::TN];
   // (the sum over the block rows before p0 was left in R, negated, by the sweep's spare filler workgroups)
-  if (item.w & LAUUM_LOAD) acc_load_neg<C>(P.R + (int64_t)i * NB * ld + j * NB, ld, acc);
+  if (item.w & LAUUM_LOAD) acc_load_neg<C>(P.R + ((int64_t)i * NB + mo) * ld + j * NB + no, ld, acc);
   else acc_zero<C>(acc);
   gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = p0 + kb;
-    if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB; lda = ld; }
-    else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB; lda = NB; }
-    if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB; ldb = ld; }
-    else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB; ldb = NB; }
+    if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB + mo; lda = ld; }
+    else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB + mo; lda = NB; }
+    if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB + no; ldb = ld; }
+    else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + no; ldb = NB; }
   }, acc);
 
 #ifdef PGM_LAUUM_NOEPI
@@ -1027,7 +1035,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
     if (sacc == 1.2345e300) P.partials[0] = 1.0; }
   return;
 #endif
-  if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc);
+  if constexpr (SUB == 1) { if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc); }
   // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
   const int Q = P.q;
   constexpr int QC = (EPI_SLOTS - D) / (3 * D);          // mixtures staged at once
@@ -1068,7 +1076,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
     for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+        const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
         const int gi = i * NB + m, gj = j * NB + n;
         const bool valid = (gi < P.n) && (gj < P.n);
         const double aa = (p0 + plen == P.nb) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
@@ -1102,7 +1110,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
             for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+                const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
                 const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
                 const double e = exp_neg(-TWO_PI_SQ * ds * ds);
                 const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
@@ -1127,7 +1135,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
         for (int tj = 0; tj < C::TN; ++tj)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int m = acc_row<C>(wp, ti, r), n = acc_col<C>(wp, tj);
+            const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
             double E[D], CC[D], SN[D], TAU[D];
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
@@ -1257,11 +1265,6 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
   }
-}
-
-// the factorisation status of every problem of the call, copied to host-mapped memory at the end of the sweep
-__global__ __launch_bounds__(256) void k_publish_info(PgmDev P, int* __restrict__ host_mapped) {
-  for (int b = threadIdx.x; b < P.batch; b += 256) host_mapped[b] = P.info[b];
 }
 
 // ---------------------------------------------------------------------------
