@@ -302,6 +302,7 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
         out["g_noise"] = buf[offs[4]:offs[5]].view(lead + (n,))
         out["g_mean"] = buf[offs[5]:offs[6]].view(lead + (n,))
     out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
+    out["_buf"], out["_offs"] = buf, offs                    # (one contiguous buffer: a caller can scale every gradient with one multiply)
     out["workspace"] = ws
     return out
 

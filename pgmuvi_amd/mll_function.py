@@ -65,16 +65,37 @@ class SMExactMLLFunction(torch.autograd.Function):
                       None if noise_scalar is None else noise_scalar.shape, w.shape, mu.shape, v.shape)
         ctx.dtypes = (y.dtype, mean.dtype, None if noise_vec is None else noise_vec.dtype,
                       None if noise_scalar is None else noise_scalar.dtype, w.dtype, mu.dtype, v.dtype)
+        ctx.offs = None
         if need_grad:
-            ctx.save_for_backward(out["g_w"], out["g_mu"], out["g_v"], out["g_noise"], out["g_mean"])
+            if y.dim() == 1 and "_buf" in out:                   # one light curve: all gradients sit in one buffer
+                ctx.save_for_backward(out["_buf"])
+                ctx.offs = out["_offs"]
+            else:
+                ctx.save_for_backward(out["g_w"], out["g_mu"], out["g_v"], out["g_noise"], out["g_mean"])
         SMExactMLLFunction.last_jitter = jitter
         return out["mll"].to(w.dtype)
 
     @staticmethod
     def backward(ctx, gout):
-        g_w, g_mu, g_v, g_noise, g_mean = ctx.saved_tensors
         ys, ms, nvs, nss, wsh, mush, vsh = ctx.shapes
         yd, md, nvd, nsd, wd, mud, vd = ctx.dtypes
+        if ctx.offs is not None:
+            # one light curve: ONE multiply scales every gradient (this runs once per training iteration on the host's
+            # critical path: each small torch op costs more host time than the arithmetic it launches)
+            (buf,) = ctx.saved_tensors
+            o = ctx.offs
+            sc = buf * gout.to(torch.float64)
+            need = ctx.needs_input_grad
+            g_noise, g_mean = sc[o[4]:o[5]], sc[o[5]:o[6]]
+            gy = (-g_mean).reshape(ys).to(yd) if need[1] else None
+            gm = g_mean.reshape(ys).sum_to_size(ms).to(md) if need[2] else None
+            gnv = g_noise.reshape(ys).sum_to_size(nvs).to(nvd) if (nvs is not None and need[3]) else None
+            gns = g_noise.sum().reshape(nss if len(nss) else ()).to(nsd) if (nss is not None and need[4]) else None
+            gw = sc[o[1]:o[2]].reshape(wsh).to(wd) if need[5] else None
+            gmu = sc[o[2]:o[3]].reshape(mush).to(mud) if need[6] else None
+            gv = sc[o[3]:o[4]].reshape(vsh).to(vd) if need[7] else None
+            return None, gy, gm, gnv, gns, gw, gmu, gv, None
+        g_w, g_mu, g_v, g_noise, g_mean = ctx.saved_tensors
         go = gout.to(torch.float64)
         gb = go.unsqueeze(-1) if go.dim() > 0 else go          # broadcast over the trailing data/param dim
         need = ctx.needs_input_grad
