@@ -105,6 +105,10 @@ def _check(rc: int, what: str):
 
 
 def _dev64(t: torch.Tensor, device) -> torch.Tensor:
+    # (the common case -- already float64, on the device, contiguous -- must cost nothing: this runs a dozen times per
+    #  training iteration while the GPU waits for the launch)
+    if t.dtype is torch.float64 and t.device == device and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
     return t.detach().to(device=device, dtype=torch.float64).contiguous()
 
 
@@ -245,6 +249,51 @@ def sm_kernel_dense(x1, x2, w, mu, v, noise=None, noise_scalar: float = 0.0, dim
     return K
 
 
+class _Outputs(dict):
+    """The result dictionary of an evaluation whose fp64 outputs share one buffer: the per-output views are made when they
+    are first asked for (a training iteration reads ``mll`` and the whole buffer only; each view costs host time while the
+    GPU waits for the next launch)."""
+
+    def __init__(self, buf, offs, layout):
+        super().__init__()
+        self._lazy = (buf, offs, layout)
+
+    def __missing__(self, key):
+        buf, offs, layout = self._lazy
+        if key not in layout:
+            raise KeyError(key)
+        i, shape = layout[key]
+        v = buf[offs[i]:offs[i + 1]].view(shape)
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy[2]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        for k in self._lazy[2]:
+            self[k]
+        return dict.items(self)
+
+    def keys(self):
+        for k in self._lazy[2]:
+            self[k]
+        return dict.keys(self)
+
+    def values(self):
+        self.keys()
+        return dict.values(self)
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+
 def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitter=0.0, need_grad=True,
                    workspace: Optional[Workspace] = None):
     """One (or a batch of) MLL evaluation(s) through the C ABI.
@@ -258,15 +307,18 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     batched = y.dim() == 2
     B = y.shape[0] if batched else 1
     n = y.shape[-1]
-    xd = _dev64(x.reshape(B, n, -1), dev)
-    d = xd.shape[-1]
+    # (the C side takes pointers: no reshapes, only float64 / device / contiguity -- and the element counts, checked here,
+    #  because a wrong size would otherwise be read out of bounds on the device)
+    xd = _dev64(x, dev)
+    d = xd.numel() // (B * n)
     q = w.shape[-1] if w.dim() > 0 else 1
-    yd = _dev64(y.reshape(B, n), dev)
-    md = _dev64(mean.expand(y.shape).reshape(B, n), dev)
-    nz = None if noise is None else _dev64(noise.expand(y.shape).reshape(B, n), dev)
-    wd = _dev64(w.reshape(B, q), dev)
-    mud = _dev64(mu.reshape(B, q, d), dev)
-    vd = _dev64(v.reshape(B, q, d), dev)
+    yd = _dev64(y, dev)
+    md = _dev64(mean if mean.shape == y.shape else mean.expand(y.shape), dev)
+    nz = None if noise is None else _dev64(noise if noise.shape == y.shape else noise.expand(y.shape), dev)
+    wd, mud, vd = _dev64(w, dev), _dev64(mu, dev), _dev64(v, dev)
+    if (xd.numel() != B * n * d or yd.numel() != B * n or wd.numel() != B * q or mud.numel() != B * q * d or vd.numel() != B * q * d):
+        raise ValueError(f"mll_value_grad: inconsistent shapes x {tuple(x.shape)} y {tuple(y.shape)} w {tuple(w.shape)} "
+                         f"mu {tuple(mu.shape)} v {tuple(v.shape)}")
     ws = workspace or get_workspace(dev, n, q, d, B)
     # every fp64 output in ONE allocation (this runs once per training iteration between two device launches: each
     # torch.empty / view costs microseconds of host time the GPU spends idle); `info` is written by every call
@@ -278,29 +330,23 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     offs = [0]
     for sz in sizes:
         offs.append(offs[-1] + sz)
-    ptr = lambda i: c_void_p(base + 8 * offs[i])
-    null = c_void_p(None)
+    gp = [base + 8 * offs[i] for i in range(6)] if need_grad else [base, None, None, None, None, None]
     lib = load()
-    st = current_stream_ptr(dev)
     # always the batched entry point (B = 1 when unbatched): the scalar noise then
     # travels as a device pointer and no host synchronisation is needed
     ns = None
     if noise_scalar is not None:
         ns = _dev64(torch.as_tensor(noise_scalar, device=dev).expand(B).reshape(B), dev)
     rc = lib.pgm_mll_value_grad_batched_f64(
-        ws.handle, B, _ptr(xd), _ptr(yd), _ptr(md), _ptr(nz), _ptr(ns), n, d, _ptr(wd), _ptr(mud), _ptr(vd), q,
+        ws.handle, B, xd.data_ptr(), yd.data_ptr(), md.data_ptr(), None if nz is None else nz.data_ptr(),
+        None if ns is None else ns.data_ptr(), n, d, wd.data_ptr(), mud.data_ptr(), vd.data_ptr(), q,
         int(dim_order), float(jitter), 1 if need_grad else 0,
-        ptr(0), ptr(1) if need_grad else null, ptr(2) if need_grad else null, ptr(3) if need_grad else null,
-        ptr(4) if need_grad else null, ptr(5) if need_grad else null, _ptr(info), st)
+        gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], info.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     _check(rc, "pgm_mll_value_grad_batched_f64")
     lead = (B,) if batched else ()
-    out = dict(mll=buf[offs[0]:offs[1]].view(lead), info=info.view(lead))
-    if need_grad:
-        out["g_w"] = buf[offs[1]:offs[2]].view(lead + (q,))
-        out["g_mu"] = buf[offs[2]:offs[3]].view(lead + (q, d))
-        out["g_v"] = buf[offs[3]:offs[4]].view(lead + (q, d))
-        out["g_noise"] = buf[offs[4]:offs[5]].view(lead + (n,))
-        out["g_mean"] = buf[offs[5]:offs[6]].view(lead + (n,))
+    out = _Outputs(buf, offs, {"mll": (0, lead), "g_w": (1, lead + (q,)), "g_mu": (2, lead + (q, d)), "g_v": (3, lead + (q, d)),
+                               "g_noise": (4, lead + (n,)), "g_mean": (5, lead + (n,))} if need_grad else {"mll": (0, lead)})
+    out["info"] = info.view(lead)
     out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
     out["_buf"], out["_offs"] = buf, offs                    # (one contiguous buffer: a caller can scale every gradient with one multiply)
     out["workspace"] = ws
