@@ -93,3 +93,19 @@ def test_workspace_cache_policy_without_a_gpu(monkeypatch):
     assert _hip.get_workspace(dev, 2000, 4, 1, 4) is c
     _hip.release_workspaces()
     assert _hip._workspaces == {} and FakeWorkspace.closed == []
+
+
+def test_lazy_result_dictionary_behaves_like_the_plain_one():
+    """``mll_value_grad`` returns its fp64 outputs as views of ONE buffer that are only made when asked for (the training
+    loop reads ``mll`` and the buffer); every way the tests and the callers read the dictionary must see all of them."""
+    import torch
+    buf = torch.arange(12.0, dtype=torch.float64)
+    out = _hip._Outputs(buf, [0, 1, 4, 12], {"mll": (0, ()), "g_w": (1, (3,)), "g_noise": (2, (2, 4))})
+    out["info"] = torch.zeros((), dtype=torch.int32)
+    assert "g_w" in out and "g_noise" in out and "g_mean" not in out and out.get("g_mean") is None
+    assert float(out["mll"]) == 0.0 and out["g_w"].tolist() == [1.0, 2.0, 3.0] and tuple(out.get("g_noise").shape) == (2, 4)
+    assert sorted(out.keys()) == ["g_noise", "g_w", "info", "mll"] and len(out) == 4 and sorted(out) == sorted(out.keys())
+    assert {k: tuple(v.shape) for k, v in out.items()} == {"mll": (), "g_w": (3,), "g_noise": (2, 4), "info": ()}
+    assert out["g_w"].data_ptr() == buf.data_ptr() + 8                     # views, not copies
+    with pytest.raises(KeyError):
+        out["g_mean"]
