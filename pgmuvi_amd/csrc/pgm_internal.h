@@ -49,6 +49,8 @@ struct PgmDev {
   double* out_gnoise; // [batch][np]
   double* out_gmean;  // [batch][np]
   int* info;          // [batch]
+  unsigned long long* outp;   // [7] the caller's output pointers of THIS evaluation (mll, g_w, g_mu, g_v, g_noise, g_mean, info), left
+                      //     in device memory by k_precompute: k_finalize, replayed from a graph, writes the results there
   int* info_host;     // host-mapped copy of `info` (device address) that the LAST diagonal-block launch fills in, or null
   double jitter, noise_scalar;
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
@@ -70,6 +72,7 @@ struct pgm_ws {
   int max_q, max_d, max_batch, max_nb;
   size_t bytes;
   double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp, *dpart, *diagadd, *out_small, *out_gnoise, *out_gmean;
+  unsigned long long* outp;
   int* info;
   int4* items;           // device copy of the work-item table
   std::vector<int4> items_host;

@@ -73,11 +73,22 @@ __device__ __forceinline__ void xcd_batch_remap(int& x, int& b) {
 // Per-point factors.  GPyTorch evaluates cos(2 pi (x_i mu - x_j mu)); the angle
 // difference is expanded (cos a cos b + sin a sin b) so the N^2 pass needs no
 // trigonometry, only the N*Q*d sincospi here.
+// The caller's output pointers of this evaluation go to device memory: k_precompute is launched with them as arguments,
+// k_finalize is replayed from a graph captured once per problem shape and reads them from there.
+__device__ __forceinline__ void publish_output_pointers(const PgmDev& P) {
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 64 && P.outp) {
+    P.outp[0] = (unsigned long long)P.mll; P.outp[1] = (unsigned long long)P.g_w; P.outp[2] = (unsigned long long)P.g_mu;
+    P.outp[3] = (unsigned long long)P.g_v; P.outp[4] = (unsigned long long)P.g_noise; P.outp[5] = (unsigned long long)P.g_mean;
+    P.outp[6] = (unsigned long long)P.info_out;
+  }
+}
+
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_precompute(PgmDev P) {
   const int b = blockIdx.z;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) P.info[b] = 0;
+  publish_output_pointers(P);
   if (blockIdx.x == 0 && threadIdx.x < P.q + 2 * P.qd) {
     const int s = threadIdx.x;
     double val;
@@ -1199,17 +1210,30 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   // (mean and noise), FIN_THREADS points each -- side by side instead of one after the other
   // (a failed factorisation leaves NaN in every output, so that no caller steps on the previous evaluation's gradients)
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  // results go to the workspace (the dense back-end and prediction read them there) and, where this evaluation's caller left
+  // its output pointers (P.outp, written by k_precompute), straight to the caller's arrays
+  double* c_mll = nullptr; double* c_gw = nullptr; double* c_gmu = nullptr; double* c_gv = nullptr;
+  double* c_gnoise = nullptr; double* c_gmean = nullptr; int* c_info = nullptr;
+  if (P.outp) {
+    c_mll = (double*)P.outp[0]; c_gw = (double*)P.outp[1]; c_gmu = (double*)P.outp[2]; c_gv = (double*)P.outp[3];
+    c_gnoise = (double*)P.outp[4]; c_gmean = (double*)P.outp[5]; c_info = (int*)P.outp[6];
+  }
   if (blockIdx.x > 0) {
     if (!P.need_grad) return;
     const double half_n = 0.5 / (double)P.n;
     const int i = ((int)blockIdx.x - 1) * FIN_THREADS + t;
     if (bad) {
-      if (i < P.n) { P.out_gmean[b * P.sVec + i] = qnan; P.out_gnoise[b * P.sVec + i] = qnan; }
+      if (i < P.n) {
+        P.out_gmean[b * P.sVec + i] = qnan; P.out_gnoise[b * P.sVec + i] = qnan;
+        if (c_gmean) c_gmean[(int64_t)b * P.n + i] = qnan;
+        if (c_gnoise) c_gnoise[(int64_t)b * P.n + i] = qnan;
+      }
       return;
     }
     if (i < P.n) {
       const double al = P.alpha[b * P.sVec + i];
       P.out_gmean[b * P.sVec + i] = al / (double)P.n;
+      if (c_gmean) c_gmean[(int64_t)b * P.n + i] = al / (double)P.n;
       double dsum = 0.0;
       if (P.ainv_from_tiles) {
         const int cnt = (P.nb - i / NB + P.ainv_from_tiles - 1) / P.ainv_from_tiles;      // work items of tile (jb, jb)
@@ -1219,6 +1243,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
         for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
       }
       P.out_gnoise[b * P.sVec + i] = half_n * (al * al - dsum);
+      if (c_gnoise) c_gnoise[(int64_t)b * P.n + i] = half_n * (al * al - dsum);
     }
     return;
   }
@@ -1231,11 +1256,20 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   if (t == 0) {
     double tot = 0.0;
     for (int wv = 0; wv < FIN_THREADS / 64; ++wv) tot += red[wv];
-    P.out_small[b * P.sOut + 0] = bad ? qnan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
+    const double val = bad ? qnan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
+    P.out_small[b * P.sOut + 0] = val;
+    if (c_mll) c_mll[b] = val;
+    if (c_info) c_info[b] = bad;
   }
   if (!P.need_grad) return;
+  // slot s of the hyper-parameter gradients in the caller's arrays: w (q), mu (q*d), v (q*d)
+  auto c_slot = [&](int s, double val) {
+    if (s < P.q) { if (c_gw) c_gw[(int64_t)b * P.q + s] = val; }
+    else if (s < P.q + P.qd) { if (c_gmu) c_gmu[(int64_t)b * P.qd + (s - P.q)] = val; }
+    else if (s < P.q + 2 * P.qd) { if (c_gv) c_gv[(int64_t)b * P.qd + (s - P.q - P.qd)] = val; }
+  };
   if (bad) {
-    if (t >= 1 && t < 1 + P.q + 2 * P.qd) P.out_small[b * P.sOut + t] = qnan;
+    if (t >= 1 && t < 1 + P.q + 2 * P.qd) { P.out_small[b * P.sOut + t] = qnan; c_slot(t - 1, qnan); }
     return;
   }
   const double half_n = 0.5 / (double)P.n;
@@ -1253,41 +1287,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     for (; tile < P.nitems; tile += 64) a0 += part[(int64_t)tile * P.nslot];
     double acc = wave_sum((a0 + a1) + (a2 + a3));   // fixed summation order: reproducible
     if (lane != 0) continue;
+    double val = 0.0;
     if (sidx < Q) {
-      P.out_small[b * P.sOut + 1 + sidx] = half_n * acc;
+      val = half_n * acc;
     } else if (sidx < Q + QD) {
       const int qd = sidx - Q, q = qd / P.d;
-      P.out_small[b * P.sOut + 1 + sidx] = half_n * (-2.0 * PI) * hyp[q] * acc;
+      val = half_n * (-2.0 * PI) * hyp[q] * acc;
     } else if (sidx < Q + 2 * QD) {
       const int qd = sidx - Q - QD, q = qd / P.d;
-      P.out_small[b * P.sOut + 1 + sidx] = half_n * (-2.0 * TWO_PI_SQ) * hyp[Q + QD + qd] * hyp[q] * acc;
+      val = half_n * (-2.0 * TWO_PI_SQ) * hyp[Q + QD + qd] * hyp[q] * acc;
     }
+    if (sidx < Q + 2 * QD) { P.out_small[b * P.sOut + 1 + sidx] = val; c_slot(sidx, val); }
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Results leave the workspace for the caller's arrays.  Together with k_precompute this is the
-// only kernel that sees caller pointers: everything in between works on workspace addresses
-// only, which is what lets the whole launch sequence be replayed as one hipGraph.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stage_out(PgmDev P) {
-  const int b = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const double* os = P.out_small + b * P.sOut;
-  if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) { P.mll[b] = os[0]; if (P.info_out) P.info_out[b] = P.info[b]; }
-    if (P.need_grad) {
-      const int s = threadIdx.x;
-      if (s < P.q) { if (P.g_w) P.g_w[(int64_t)b * P.q + s] = os[1 + s]; }
-      else if (s < P.q + P.qd) { if (P.g_mu) P.g_mu[(int64_t)b * P.qd + (s - P.q)] = os[1 + s]; }
-      else if (s < P.q + 2 * P.qd) { if (P.g_v) P.g_v[(int64_t)b * P.qd + (s - P.q - P.qd)] = os[1 + s]; }
-    }
-  }
-  if (P.need_grad && i < P.n) {
-    if (P.g_mean) P.g_mean[(int64_t)b * P.n + i] = P.out_gmean[b * P.sVec + i];
-    if (P.g_noise) P.g_noise[(int64_t)b * P.n + i] = P.out_gnoise[b * P.sVec + i];
   }
 }
 
