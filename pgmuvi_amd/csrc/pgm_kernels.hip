@@ -163,13 +163,14 @@ __device__ __forceinline__ double sm_pair(const double* rowd, const double* cold
 // with the identity.  One workgroup per 128x128 tile; a wave stores one full row
 // (1 KiB) per instruction.
 // ---------------------------------------------------------------------------
-constexpr int BUILD_SPLIT_1D = 4;
-template <int D, int ORDER>
+constexpr int BUILD_SPLIT_1D = 4, BUILD_SPLIT_SMALL = 16;
+template <int D, int ORDER, int SPLIT1 = BUILD_SPLIT_1D>
 __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   const int b = blockIdx.z;
   int ib, jb;
-  // (1-D: a workgroup builds a quarter of a tile, 32 rows: 2112 workgroups even out over the 256 CUs where 528 did not)
-  constexpr int SPLIT = (D == 1) ? BUILD_SPLIT_1D : 1;
+  // (1-D: a workgroup builds a quarter of a tile, 32 rows: 2112 workgroups even out over the 256 CUs where 528 did not;
+  //  a sixteenth, 8 rows, when the whole call has only a few tiles -- short light curves: 9 -> 5 us at N=128)
+  constexpr int SPLIT = (D == 1) ? SPLIT1 : 1;
   const int part = blockIdx.x % SPLIT;
   tri_decode(blockIdx.x / SPLIT, ib, jb);
   extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD doubles
