@@ -632,13 +632,17 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
       const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
       if (row >= DB || c2 >= DB) *reinterpret_cast<v2d*>(M + row * PM + c2) = tmp[u];
     }
-    if (t < NB) { rsv[t] = rk; alv[t] = 0.0; }
+    if (t < NB) { rsv[t] = rk; alv[t] = 0.0; zsv[t] = 0.0; }
   }   // (the zero triangles of the inverse images are cleared once, at workspace creation)
   STAMP();
   constexpr int NS = NB / DB;
+  // The last block of a light curve whose length is no multiple of 128 ends in identity padding, decoupled from the data:
+  // the sub-block steps that would "factor" it are left out (N=89: 6 of 8 steps), its inverse images are stored as they are.
+  const int valid = (P.n - k * NB < NB) ? P.n - k * NB : NB;
+  const int nse = __builtin_amdgcn_readfirstlane((valid + DB - 1) / DB);
   double lgsum = 0.0;          // (bookkeeping wave)
   int firstbad = -1;
-  for (int s = 0; s < NS; ++s) {
+  for (int s = 0; s < nse; ++s) {
     lds_barrier();
     STAMP();
 #ifdef PGM_DIAG_STAMPS
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
 #endif
     // ---- (c) trailing sub-blocks; wave 0 runs ahead on the next diagonal sub-block
     if (wave == 0) {
-      if (s + 1 < NS) {
+      if (s + 1 < nse) {
         diag_update(c, s, s + 1, s + 1, lane);
         STAMP();
         diag_potrf16(c, s + 1, lane);
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
           if (badm && firstbad < 0) firstbad = s * DB + (int)__builtin_ctzll(badm);
           if (lane < DB) lgsum += 2.0 * log(u);
         }
-        if (s == NS - 1) {                                  // z_k, alpha_k, log det, info: final now
+        if (s == nse - 1) {                                 // z_k, alpha_k, log det, info: final now
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             P.z[b * P.sVec + k * NB + lane + 64 * u] = zsv[lane + 64 * u];
@@ -734,6 +738,12 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
 #ifdef PGM_DIAG_STAMPS
     if (lane == 0 && k == 0 && s < 4) { P.partials[64 + wave * 16 + s * 2] = (double)(wb1_ - wb0_); P.partials[64 + wave * 16 + s * 2 + 1] = (double)(__builtin_amdgcn_s_memtime() - wc0_); }
 #endif
+  }
+  if (nse < NS) {                                             // inverse images of the padding: zero blocks and identities, as they stand
+    lds_barrier();
+    if (wave >= 1 && wave < DIAG_WAVES - 1)
+      for (int s = nse; s < NS; ++s)
+        if (wave - 1 <= s && wave - 1 < NS) diag_store_vblock(c, s, wave - 1, lane);
   }
 #ifdef PGM_DIAG_STAMPS
   STAMP();
