@@ -1238,6 +1238,37 @@ def test_look_ahead_is_bit_for_bit_the_three_launch_chain(dev, monkeypatch, n, b
             assert _rel(outs["0"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
+@pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 4223])
+def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, n):
+    """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
+    schedule and through the plainest one -- three-launch chain, whole-tile inverse pass, no early inverse products: the same
+    factor, hence the same value bit for bit; gradients to the rounding of their differently split sums; both against the
+    oracle where it is quick."""
+    gen = torch.Generator().manual_seed(n)
+    x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 1200)[0]
+    y = torch.randn(n, generator=gen, dtype=D)
+    nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+    w = torch.tensor([0.7, 0.25], dtype=D); mu = torch.tensor([[0.013], [0.21]], dtype=D); v = torch.tensor([[0.004], [0.015]], dtype=D)
+    outs = {}
+    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0"})):
+        _hip.release_workspaces()
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        outs[name] = {k: t.clone().cpu() for k, t in _hip_eval(dev, x, y, -0.2, nz, w, mu, v).items() if torch.is_tensor(t)}
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    _hip.release_workspaces()
+    assert int(outs["default"]["info"]) == 0 and torch.equal(outs["default"]["mll"], outs["plain"]["mll"])
+    assert torch.equal(outs["default"]["g_mean"], outs["plain"]["g_mean"])
+    for p in ("w", "mu", "v", "noise"):
+        assert _rel(outs["default"][f"g_{p}"].reshape(-1), outs["plain"][f"g_{p}"].reshape(-1)) < 1e-11, p
+    if n <= 1409:
+        val, gr = orc.mll_value_grad_closed_form(x, y, -0.2, nz, w, mu, v, 0, 0.0)
+        assert abs(float(outs["default"]["mll"]) - float(val)) < MLL_TOL
+        for p in ("w", "mu", "v", "noise", "mean"):
+            assert _rel(outs["default"][f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
 def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatch):
     """34..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
     the diagonal-block launches), the rows beyond it get one deep update per window.  Same factor, hence the same value bit
