@@ -101,7 +101,7 @@ struct pgm_ws {
   int4* early_items;     // device copy
   int early_cap, early_final_n;
   double* Rbuf; size_t R_bytes;
-  // hipGraph replay of the launch sequence between k_precompute and k_stage_out
+  // hipGraph replay of the launch sequence behind k_precompute
   bool use_graph;
   hipStream_t cap_stream;
   struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; int parts; hipGraphExec_t exec; };

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   const int b = blockIdx.z;
   // (no early exit on P.info here or in k_trsm / k_update: after a failed pivot the chain kernels just
   //  carry NaNs -- no address depends on data -- and a dependent scalar load in front of every one of the
-  //  ~95 chained launches costs 0.4 us each, 1.5 % of an evaluation)
+  //  ~65 chained launches costs 0.4 us each, 1 % of an evaluation)
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
   __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], dump[64], pbuf[4 * 32];
