@@ -77,7 +77,7 @@ __device__ __forceinline__ int acc_col(const WavePos& p, int tj) { return p.n0 +
 // separate column slabs multiplied as one operand).
 template <class C, class PtrFn>
 __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn&& ptrs,
-                                        v4d (&acc)[C::TM][C::TN], int bsplit = 0) {
+                                        v4d (&acc)[C::TM][C::TN], int bsplit = 0, bool negate_late = false) {
   const int t = threadIdx.x;
   const WavePos wp = wave_pos<C>();
   constexpr int KC = C::KC;
@@ -118,6 +118,12 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
   // register set u holds chunk c with c % D == u; LDS is double-buffered
 #pragma unroll
   for (int u = 0; u < D; ++u) gload(u, ra[u], rb[u]);       // nchunks >= 8 >= D
+  if (negate_late) {                                        // acc holds +C from acc_load_raw: its loads and the first chunks' are
+#pragma unroll                                              // one memory round trip instead of two
+    for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj] = -acc[ti][tj];
+  }
   sstore(0, ra[0], rb[0]);
   __syncthreads();
   for (int c0 = 0; c0 < nchunks; c0 += D) {
@@ -158,6 +164,25 @@ __device__ __forceinline__ void acc_load_neg(const double* __restrict__ c, int64
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         acc[ti][tj][r] = -c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)];
+}
+// acc = +C, to be negated by gemm_tn(..., negate_late = true) once the first operand chunks are on their way
+template <class C>
+__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) {
+  const WavePos wp = wave_pos<C>();
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[ti][tj][r] = c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)];
+}
+template <class C>
+__device__ __forceinline__ void acc_negate(v4d (&acc)[C::TM][C::TN]) {
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj] = -acc[ti][tj];
 }
 template <class C>
 __device__ __forceinline__ void acc_zero(v4d (&acc)[C::TM][C::TN]) {

@@ -524,15 +524,17 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
   const double* pa1 = pa0 + NB * ld;
   const double* pb1 = A + (int64_t)(pstart + 1) * NB * ld + j * NB + sj * C::BN;
   v4d acc[C::TM][C::TN];
-  if (assign) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
+  if (assign) acc_zero<C>(acc); else acc_load_raw<C>(Cp, ld, acc);   // (negated inside gemm_tn: see negate_late there)
   if (nkb == 1) {
     gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
       pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
-    }, acc);
+    }, acc, 0, !assign);
   } else if (nkb == 2) {                                     // two sources (the host never plans more)
     gemm_tn<C>(lds, 2, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
       pa = kb ? pa1 : pa0; lda = ld; pb = kb ? pb1 : pb0; ldb = kb ? ld : ldb0;
-    }, acc);
+    }, acc, 0, !assign);
+  } else if (!assign) {                                      // (copy only)
+    acc_negate<C>(acc);
   }
   if (!copy_only) acc_store<C>(Cp, ld, acc, -1.0);
   if (own && syrk && tile == 0)                              // (uniform) the tile the coming row solve's look-ahead reads
@@ -552,10 +554,11 @@ __device__ __forceinline__ void early_inverse_tile(const PgmDev& P, double* lds,
   const double* pb0 = (p > j) ? P.A + (int64_t)p * NB * ld + j * NB : P.Dinv + ((int64_t)j * 2 + 1) * NB * NB;
   const int64_t lda0 = (p > i) ? ld : NB, ldb0 = (p > j) ? ld : NB;
   v4d acc[C::TM][C::TN];
-  if (task.w & LAUUM_LOAD) acc_load_neg<C>(Rp, ld, acc); else acc_zero<C>(acc);
+  const bool cont = (task.w & LAUUM_LOAD) != 0;
+  if (cont) acc_load_raw<C>(Rp, ld, acc); else acc_zero<C>(acc);
   gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     pa = pa0; lda = lda0; pb = pb0; ldb = ldb0;
-  }, acc);
+  }, acc, 0, cont);
   acc_store<C>(Rp, ld, acc, -1.0);
 }
 
@@ -923,13 +926,13 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
   double* Cp = A + ((int64_t)r * NB + si * C::BM) * ld + j * NB + sj * C::BN;
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   v4d acc[C::TM][C::TN];
-  if (assign) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
+  if (assign) acc_zero<C>(acc); else acc_load_raw<C>(Cp, ld, acc);   // (negated inside gemm_tn: see negate_late there)
   gemm_tn<C>(lds, kend - pstart + 1, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = pstart + kb;
     pa = A + (int64_t)p * NB * ld + r * NB + si * C::BM; lda = ld;
     if (!syrk && p == j) { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + sj * C::BN; ldb = NB; }
     else { pb = A + (int64_t)p * NB * ld + j * NB + sj * C::BN; ldb = ld; }
-  }, acc);
+  }, acc, 0, !assign);
   acc_store<C>(Cp, ld, acc, -1.0);
 }
 
@@ -1038,7 +1041,8 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   const int64_t ld = P.ld;
   v4d acc[C::TM][C::TN];
   // (the sum over the block rows before p0 was left in R, negated, by the sweep's spare filler workgroups)
-  if (item.w & LAUUM_LOAD) acc_load_neg<C>(P.R + ((int64_t)i * NB + mo) * ld + j * NB + no, ld, acc);
+  const bool cont = (item.w & LAUUM_LOAD) != 0;
+  if (cont) acc_load_raw<C>(P.R + ((int64_t)i * NB + mo) * ld + j * NB + no, ld, acc);   // (negated inside gemm_tn)
   else acc_zero<C>(acc);
   gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = p0 + kb;
@@ -1046,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
     else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB + mo; lda = NB; }
     if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB + no; ldb = ld; }
     else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + no; ldb = NB; }
-  }, acc);
+  }, acc, 0, cont);
 
 #ifdef PGM_LAUUM_NOEPI
   { double sacc = 0.0;                                       // (timing experiment: multiply loop only)
@@ -1481,7 +1485,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_probe(const double* A, int64_t 
 
 // Tile-product probe (tools only): workgroup t does what a trailing-update tile does -- reads its C tile, multiplies `nkb`
 // k-blocks of two operand panels, writes the tile back -- on a synthetic 24-column arrangement of distinct tiles.
-template <class C, int WPS>
+// MODE bit 0: the C tile is not read (accumulation from zero), bit 1: it is not written, bit 2: it is read
+// unnegated and negated only after the first operand chunks were requested (one memory round trip instead of two).
+template <class C, int WPS, int MODE = 0>
 __global__ __launch_bounds__(C::NT, WPS) void k_tile_probe(double* A, int64_t ld, int nkb) {
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   constexpr int SUBM = NB / C::BM, SUBN = NB / C::BN;
@@ -1489,13 +1495,14 @@ __global__ __launch_bounds__(C::NT, WPS) void k_tile_probe(double* A, int64_t ld
   const int r = 8 + t / 24, j = t % 24, si = sub / SUBN, sj = sub % SUBN;
   double* Cp = A + ((int64_t)r * NB + si * C::BM) * ld + j * NB + sj * C::BN;
   v4d acc[C::TM][C::TN];
-  acc_load_neg<C>(Cp, ld, acc);
+  if (MODE & 4) acc_load_raw<C>(Cp, ld, acc);
+  else if (MODE & 1) acc_zero<C>(acc); else acc_load_neg<C>(Cp, ld, acc);
   const double* pa0 = A + (int64_t)(r - 8) * NB + si * C::BM;
   const double* pb0 = A + (int64_t)j * NB + sj * C::BN;
   gemm_tn<C>(lds, nkb, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     pa = pa0 + (int64_t)kb * NB * ld; lda = ld; pb = pb0 + (int64_t)kb * NB * ld; ldb = ld;
-  }, acc);
-  acc_store<C>(Cp, ld, acc, -1.0);
+  }, acc, 0, (MODE & 4) != 0);
+  if (MODE & 2) { if (acc[0][0][0] == 1.2345e300) Cp[0] = 0.0; } else acc_store<C>(Cp, ld, acc, -1.0);
 }
 
 // ---------------------------------------------------------------------------

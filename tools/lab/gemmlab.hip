@@ -163,6 +163,35 @@ void run_dma(const char* name, const double* A, int64_t ld, double* out, int blo
   printf("%-64s blocks %4d nkb %2d: %8.1f us  %6.2f TFLOP/s = %.3f of 78.6%s\n", name, blocks, nkb, ms * 1e3, tf, tf / 78.6, hipGetLastError() == hipSuccess ? "" : " FAILED");
 }
 
+// cold operands: every workgroup multiplies k-blocks of its own (rows that no other workgroup touches, 1 GB in all)
+template <class C, int WPS>
+__global__ __launch_bounds__(C::NT, WPS) void k_lab_cold(const double* A, int64_t ld, int nkb, int64_t rows, double* out) {
+  __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
+  v4d acc[C::TM][C::TN];
+  acc_zero<C>(acc);
+  const int64_t r0 = ((int64_t)blockIdx.x * nkb * NB) % (rows - (int64_t)nkb * NB);
+  const int64_t c0 = (blockIdx.x % 8) * 2 * C::BM;
+  gemm_lab<C, true, true, true>(lds, nkb, A + r0 * ld + c0, A + r0 * ld + c0 + C::BM, ld, acc);
+  double s = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) s += acc[ti][tj][0] + acc[ti][tj][3];
+  if (s == 1.2345) out[0] = s;
+}
+template <class C, int WPS>
+void run_cold(const char* name, const double* A, int64_t ld, int64_t rows, double* out, int blocks, int nkb) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 6; ++rep) {
+    if (rep == 1) hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_lab_cold<C, WPS>), dim3(blocks), dim3(C::NT), 0, 0, A, ld, nkb, rows, out);
+  }
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  const double tf = 2.0 * C::BM * C::BN * NB * nkb * blocks / (ms * 1e-3) / 1e12;
+  printf("%-64s blocks %4d nkb %2d: %8.1f us  %6.2f TFLOP/s = %.3f of 78.6%s\n", name, blocks, nkb, ms * 1e3, tf, tf / 78.6, hipGetLastError() == hipSuccess ? "" : " FAILED");
+}
+
 template <class C, int WPS, bool G, bool S, bool B>
 void run(const char* name, const double* A, int64_t ld, double* out, int blocks, int nkb) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -194,6 +223,22 @@ int main() {
     hipLaunchKernelGGL((k_lab_dma<Big, 2>), dim3(1), dim3(256), 0, 0, A, ld, 1, out); hipMemcpy(r2.data(), out + 8, 256 * 8, hipMemcpyDeviceToHost);
     double md = 0; for (int i = 0; i < 256; ++i) md = std::max(md, std::abs(r1[i] - r2[i]));
     printf("LDS-DMA loop vs register-staged loop: max |difference| %.3e (values ~%.3e)\n", md, r1[0]);
+  }
+  {  // operands streamed from memory nobody else touches (1 GB: beyond the L2s and most of the Infinity Cache)
+    const int64_t rows = 32768;
+    double* Acold = nullptr;
+    if (hipMalloc(&Acold, sizeof(double) * ld * rows) == hipSuccess) {
+      hipMemset(Acold, 0, sizeof(double) * ld * rows);
+      using F16p4 = TileCfg<128, 128, 32, 32, 4, 1024, 16>;
+      using Big4 = TileCfg<128, 128, 64, 64, 4>;
+      for (int nkb : {2, 4}) {
+        run_cold<F16, 4>("COLD operands, 16 waves 32x32/wave PF2, 1 WG/CU", Acold, ld, rows, out, 255, nkb);
+        run_cold<F16p4, 4>("COLD operands, 16 waves 32x32/wave PF4, 1 WG/CU", Acold, ld, rows, out, 255, nkb);
+        run_cold<Big, 2>("COLD operands, 4 waves 64x64/wave PF2, 2 WG/CU", Acold, ld, rows, out, 510, nkb);
+        run_cold<Big4, 2>("COLD operands, 4 waves 64x64/wave PF4, 2 WG/CU", Acold, ld, rows, out, 510, nkb);
+      }
+      hipFree(Acold);
+    }
   }
   for (int nkb : {4, 16}) {
     run_dma<Big, 2>("4 waves 64x64/wave, LDS-DMA staging, 2 WG/CU", A, ld, out, 512, nkb);

@@ -10,8 +10,11 @@ int main() {
   if (pgm_workspace_create(&ws, 0, 4096, 4, 1, 1) != 0) { printf("no workspace\n"); return 1; }
   const char* names[] = {"16 waves 128x128 (32x32 each), 1/CU, PF1", "16 waves 128x128, PF2", "8 waves 128x128 (64x32 each), 2/CU, PF1",
                          "4 waves 128x128 (64x64 each), 2/CU, PF2", "8 waves 64x64 sub-tiles (32x16 each)", "4 waves 64x64 sub-tiles (32x32 each)",
-                         "8 waves 128x128 (64x32 each), 1/CU by registers, PF2"};
-  for (int cfg = 0; cfg < 7; ++cfg)
+                         "8 waves 128x128 (64x32 each), 1/CU by registers, PF2", "16 waves 128x128, PF2, C tile not read",
+                         "16 waves 128x128, PF2, C tile not written", "16 waves 128x128, PF2, C tile neither read nor written",
+                         "16 waves 128x128, PF2, C tile negated late", "4 waves 128x128 (64x64 each), 2/CU, C tile negated late",
+                         "8 waves 64x64 sub-tiles, C tile negated late"};
+  for (int cfg = 0; cfg < 13; ++cfg)
     for (int tiles : {255, 510})
       for (int nkb : {1, 2}) {
         double us = 0.0;
