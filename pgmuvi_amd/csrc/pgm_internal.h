@@ -86,6 +86,8 @@ struct pgm_ws {
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
+  int lazy, lazy_end;    // fused sweep: lazy plan (run_sweep), and the tile count from which it turns eager
+  int plan_dump;         // PGM_PLAN_DUMP=1: run_sweep prints its plan (the first evaluation of a problem size: graphs replay silently)
   int lookahead;         // fused sweep: first block row whose successor's diagonal tile is formed inside the row-solve launch
                          //   (no head launch on the chain from there on); >= 64: never
   double* crit;          // (inside the Dinv allocation)

@@ -480,8 +480,10 @@ static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit
 // other tiles take their last sources here, the (own, own) tile is left out) -- the tile next to the diagonal, (own, own+1),
 // is also copied to P.crit, where the following row-solve launch's diagonal-tile workgroups read it while the row solve
 // overwrites it in place; own_zero: the row has nothing pending, only that copy is made.
+// `dg` >= 0: one more tile after the planned rows', the diagonal tile of block row dg alone (one source, or two with dg_two):
+// the look-ahead of the coming row solve needs that tile up to date, the rest of its row may stay behind (run_sweep).
 constexpr int FILL_MAX_NB = 48;
-struct FillPlan { unsigned long long skip, two; int own, own_zero; };
+struct FillPlan { unsigned long long skip, two; int own, own_zero, dg, dg_two; };
 
 // One planned trailing-update tile (or BM x BN sub-tile of it): workgroup index widx counts the sub-tiles of
 // the planned rows >= r_from in row order.  Used by the filler workgroups of k_diag (128x128, 16 wavefronts)
@@ -501,12 +503,16 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
     if (tile < cnt) break;
     tile -= cnt;
   }
-  if (r >= P.nb) return;                                     // (uniform for the workgroup)
+  bool dgt = false;
+  if (r >= P.nb) {                                           // (uniform for the workgroup)
+    if (plan.dg < 0 || tile != 0) return;
+    r = plan.dg; dgt = true;                                 // tile 0 of a row that is not `own` = its diagonal tile
+  }
   r = __builtin_amdgcn_readfirstlane(r);
   tile = __builtin_amdgcn_readfirstlane(tile);
-  const int own = (r == plan.own) ? 1 : 0;
+  const int own = (!dgt && r == plan.own) ? 1 : 0;
   const bool copy_only = own && plan.own_zero;
-  const int lo = copy_only ? k_end : k_end - 1 - (int)((plan.two >> r) & 1ull);
+  const int lo = copy_only ? k_end : k_end - 1 - (dgt ? plan.dg_two : (int)((plan.two >> r) & 1ull));
   const bool syrk = tile < P.nb - r - own;
   const int j = syrk ? r + own + tile : tile - (P.nb - r - own);
   const int pstart = (!syrk && j > lo) ? j : lo;             // V_pj vanishes for p < j

@@ -1238,11 +1238,43 @@ def test_look_ahead_is_bit_for_bit_the_three_launch_chain(dev, monkeypatch, n, b
             assert _rel(outs["0"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
-@pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 4223])
+@pytest.mark.parametrize("n,batch,need_grad", [(4000, 1, True), (4000, 1, False), (2040, 3, True), (3100, 2, True)])
+def test_lazy_plan_of_the_update_tiles_is_bit_for_bit_the_eager_one(dev, monkeypatch, n, batch, need_grad):
+    """Fused sweep with more update tiles than CUs: the default plan lets block rows fall two sources behind and take them in
+    one pass (only the diagonal tile of the next row is kept up to date on its own), PGM_LAZY=0 updates every row as early as
+    it can.  Every tile still receives its sources in ascending order from -C, so the factor, the value and the residual
+    gradients agree bit for bit; the spectral-mixture gradients to the rounding of the differently split inverse pass."""
+    gen = torch.Generator().manual_seed(7 * n + batch)
+    xs, ys, zs = [], [], []
+    for _ in range(batch):
+        xs.append(torch.sort(torch.rand(n, generator=gen, dtype=D) * 1500)[0]); ys.append(torch.randn(n, generator=gen, dtype=D))
+        zs.append(0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D))
+    w = torch.tensor([0.6, 0.3, 0.2], dtype=D); mu = torch.tensor([[0.02], [0.11], [0.3]], dtype=D); v = torch.tensor([[0.003], [0.01], [0.02]], dtype=D)
+    outs = {}
+    for lz in ("1", "0"):
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_LAZY", lz)
+        X, Y, Z = (torch.stack(a).to(dev) for a in (xs, ys, zs))
+        o = _hip.mll_value_grad(X.unsqueeze(-1), Y, torch.full_like(Y, 0.1), Z, None, w.to(dev).expand(batch, -1).contiguous(),
+                                mu.to(dev).expand(batch, -1, -1).contiguous(), v.to(dev).expand(batch, -1, -1).contiguous(), 0, 0.0, need_grad)
+        torch.cuda.synchronize()
+        outs[lz] = {k: t.clone().cpu() for k, t in o.items() if torch.is_tensor(t)}
+    monkeypatch.delenv("PGM_LAZY")
+    _hip.release_workspaces()
+    assert int(outs["1"]["info"].abs().sum()) == 0 and torch.isfinite(outs["1"]["mll"]).all()
+    assert torch.equal(outs["1"]["mll"], outs["0"]["mll"])
+    if need_grad:
+        assert torch.equal(outs["1"]["g_mean"], outs["0"]["g_mean"])
+        for p in ("w", "mu", "v", "noise"):
+            assert _rel(outs["1"][f"g_{p}"].reshape(-1), outs["0"][f"g_{p}"].reshape(-1)) < 1e-11, p
+
+
+@pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 3970, 4223])
 def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, n):
     """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
-    schedule and through the plainest one -- three-launch chain, whole-tile inverse pass, no early inverse products: the same
-    factor, hence the same value bit for bit; gradients to the rounding of their differently split sums; both against the
+    schedule and through the plainest one -- three-launch chain, eager plan of the update tiles (the default lets block rows
+    fall two sources behind from 32 block rows on, n = 3970, and inside the windows of n = 4223), whole-tile inverse pass, no
+    early inverse products: the same factor, hence the same value bit for bit; gradients to the rounding of their differently split sums; both against the
     oracle where it is quick."""
     gen = torch.Generator().manual_seed(n)
     x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 1200)[0]
@@ -1250,7 +1282,7 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
     nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
     w = torch.tensor([0.7, 0.25], dtype=D); mu = torch.tensor([[0.013], [0.21]], dtype=D); v = torch.tensor([[0.004], [0.015]], dtype=D)
     outs = {}
-    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0"})):
+    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0"})):
         _hip.release_workspaces()
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
