@@ -1269,11 +1269,11 @@ def test_lazy_plan_of_the_update_tiles_is_bit_for_bit_the_eager_one(dev, monkeyp
             assert _rel(outs["1"][f"g_{p}"].reshape(-1), outs["0"][f"g_{p}"].reshape(-1)) < 1e-11, p
 
 
-@pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 3970, 4223])
+@pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 3970, 5120, 5130])
 def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, n):
     """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
     schedule and through the plainest one -- three-launch chain, eager plan of the update tiles (the default lets block rows
-    fall two sources behind from 32 block rows on, n = 3970, and inside the windows of n = 4223), whole-tile inverse pass, no
+    fall two sources behind from 32 block rows on: n = 3970, the last fused size 5120, and inside the windows of 5130), whole-tile inverse pass, no
     early inverse products: the same factor, hence the same value bit for bit; gradients to the rounding of their differently split sums; both against the
     oracle where it is quick."""
     gen = torch.Generator().manual_seed(n)
