@@ -13,8 +13,9 @@ int main() {
                          "8 waves 128x128 (64x32 each), 1/CU by registers, PF2", "16 waves 128x128, PF2, C tile not read",
                          "16 waves 128x128, PF2, C tile not written", "16 waves 128x128, PF2, C tile neither read nor written",
                          "16 waves 128x128, PF2, C tile negated late", "4 waves 128x128 (64x64 each), 2/CU, C tile negated late",
-                         "8 waves 64x64 sub-tiles, C tile negated late"};
-  for (int cfg = 0; cfg < 13; ++cfg)
+                         "8 waves 64x64 sub-tiles, C tile negated late", "16 waves 128x128, PF2, 32-row chunks, negated late",
+                         "16 waves 128x128, PF4, 16-row chunks, negated late", "16 waves 128x128, PF4, 8-row chunks, negated late"};
+  for (int cfg = 0; cfg < 16; ++cfg)
     for (int tiles : {255, 510})
       for (int nkb : {1, 2}) {
         double us = 0.0;
