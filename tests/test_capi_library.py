@@ -109,3 +109,47 @@ def test_lazy_result_dictionary_behaves_like_the_plain_one():
     assert out["g_w"].data_ptr() == buf.data_ptr() + 8                     # views, not copies
     with pytest.raises(KeyError):
         out["g_mean"]
+
+
+def _plan_check():
+    f = ctypes.CDLL(_hip.lib_path()).pgm_debug_plan_check
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int] * 9
+    return f
+
+
+def test_sweep_plans_are_valid_for_every_shape():
+    """Host logic of the factorisation sweep, no GPU: `pgm_debug_plan_check` runs the planner of `run_sweep` dry (nothing is
+    launched) and replays the plan -- the row masks, the `own` row, the lone diagonal tile -- through a restatement of the
+    kernels' tile decode on a table of 'next source this tile expects'.  Valid = every tile receives the finished block rows in
+    ascending order, none twice, none skipped (a row three behind would silently lose a source: the kernels apply at most two
+    per pass); every block row is complete when its diagonal block / row solve starts; the look-ahead finds its copy of tile
+    (k, k+1) and an up-to-date diagonal tile (k+1, k+1) and never shares a launch with tail tiles of that row.  All block-row
+    counts up to 64 (N = 8192), batch sizes, value-only, look-ahead on / off / switched in mid-sweep, lazy / eager plan,
+    fused / panels / windowed."""
+    f = _plan_check()
+    bad, n = [], 0
+    for nb in range(1, 65):
+        for batch in (1, 2, 3, 5, 8, 16, 48, 64):
+            for need_grad in (0, 1):
+                for lookahead in (0, 5, 99):
+                    for lazy in (0, 1):
+                        for panel, window in ((-1, -1), (0, -1), (4, -1), (-1, 0), (-1, 8)):
+                            e = f(nb, batch, need_grad, lookahead, lazy, panel, window, 0, 0)
+                            n += 1
+                            if e != 0:
+                                bad.append((nb, batch, need_grad, lookahead, lazy, panel, window, e))
+    assert n == 64 * 8 * 2 * 3 * 2 * 5 and not bad, bad[:10]
+    assert f(0, 1, 1, 0, 1, -1, -1, 0, 0) == -1 and f(32, 0, 1, 0, 1, -1, -1, 0, 0) == -1
+
+
+def test_the_plan_check_notices_a_damaged_plan():
+    """The check's own test: with the planner damaged inside the dry run (mutate = 1: the lone diagonal-tile entry is
+    forgotten; 2: block rows may fall three sources behind) the replay reports violations exactly where the lazy plan is in
+    use (32 block rows and more), and none for the intact planner."""
+    f = _plan_check()
+    for nb in (32, 36, 40):
+        assert f(nb, 1, 1, 0, 1, -1, -1, 0, 0) == 0
+        assert f(nb, 1, 1, 0, 1, -1, -1, 0, 1) > 0
+        assert f(nb, 1, 1, 0, 1, -1, -1, 0, 2) > 0
+    assert f(8, 1, 1, 0, 1, -1, -1, 0, 1) == 0                  # (every row fits every launch: nothing lazy to damage)
