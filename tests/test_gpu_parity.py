@@ -1302,7 +1302,7 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
 
 
 def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatch):
-    """34..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
+    """41..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
     the diagonal-block launches), the rows beyond it get one deep update per window.  Same factor, hence the same value bit
     for bit, as the plain panel schedule (PGM_WINDOW=0) and as the early inverse pass switched off; gradients to rounding
     of the different summation split; and the directional derivative along the gradient matches central differences."""
