@@ -59,6 +59,7 @@ struct PgmDev {
   int ainv_from_tiles; // k-blocks per work item (0 = off): diag(A^-1) is taken from the accumulators of the (j, j) tiles' work items
                       //    in the inverse/gradient launch (item number s of the tile -> dpart row s) and the separate column-sum
                       //    pass over V is skipped
+  int build_beside;   // 1: k_build builds block row 0 only, the rest of the matrix is built by the spare workgroups of diagonal block 0's launch
   int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups)
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
   KProg prog;
@@ -86,6 +87,7 @@ struct pgm_ws {
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
+  int build_beside;      // one light curve, 1-D spectral mixture: build the matrix below block row 0 beside diagonal block 0 (PGM_BUILD_BESIDE=0: off)
   int lazy, lazy_end;    // fused sweep: lazy plan (run_sweep), and the tile count from which it turns eager
   int plan_dump;         // PGM_PLAN_DUMP=1: run_sweep prints its plan (the first evaluation of a problem size: graphs replay silently)
   int lookahead;         // fused sweep: first block row whose successor's diagonal tile is formed inside the row-solve launch

@@ -164,26 +164,13 @@ __device__ __forceinline__ double sm_pair(const double* rowd, const double* cold
 // (1 KiB) per instruction.
 // ---------------------------------------------------------------------------
 constexpr int BUILD_SPLIT_1D = 4, BUILD_SPLIT_SMALL = 16;
-template <int D, int ORDER, int SPLIT1 = BUILD_SPLIT_1D>
-__global__ __launch_bounds__(256) void k_build(PgmDev P) {
-  const int b = blockIdx.z;
-  int ib, jb;
-  // (1-D: a workgroup builds a quarter of a tile, 32 rows: 2112 workgroups even out over the 256 CUs where 528 did not;
-  //  a sixteenth, 8 rows, when the whole call has only a few tiles -- short light curves: 9 -> 5 us at N=128)
-  constexpr int SPLIT = (D == 1) ? SPLIT1 : 1;
-  const int part = blockIdx.x % SPLIT;
-  tri_decode(blockIdx.x / SPLIT, ib, jb);
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD doubles
-  double* rowd = sm;
-  double* cold = sm + P.pre_slots * NB;
-  double* wl = cold + P.pre_slots * NB;
-  const double* pre = P.pre + b * P.sPre;
-  stage_factors(P, pre, ib, jb, rowd, cold);
-  if (threadIdx.x < P.q) wl[threadIdx.x] = P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + threadIdx.x];
-  __syncthreads();
+// 1-D kernel matrix: 1/SPLIT of the tile (ib, jb) -- rows part*NB/SPLIT ... -- by 256 threads (tid), factors staged in LDS.
+// Shared by k_build and by the build workers beside diagonal block 0 (k_diag).
+template <int SPLIT>
+__device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* rowd, const double* cold, const double* wl,
+                                              int b, int ib, int jb, int part, int tid) {
   double* A = P.A + b * P.sA;
-  const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
-  if (D == 1) {
+  const int c2 = (tid & 63) * 2, rg = tid >> 6;
     // 1-D: mixtures outermost, the thread's two column factors in registers, its 32 x 2 entries accumulated in
     // registers: three LDS reads (the row's factors, broadcast) per two entries and mixture instead of nine
     constexpr int RR = NB / 4 / SPLIT;                     // rows per thread
@@ -220,6 +207,31 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
       }
       *reinterpret_cast<v2d*>(A + (int64_t)gi * P.ld + jb * NB + c2) = out;
     }
+}
+
+
+template <int D, int ORDER, int SPLIT1 = BUILD_SPLIT_1D>
+__global__ __launch_bounds__(256) void k_build(PgmDev P) {
+  const int b = blockIdx.z;
+  int ib, jb;
+  // (1-D: a workgroup builds a quarter of a tile, 32 rows: 2112 workgroups even out over the 256 CUs where 528 did not;
+  //  a sixteenth, 8 rows, when the whole call has only a few tiles -- short light curves: 9 -> 5 us at N=128)
+  constexpr int SPLIT = (D == 1) ? SPLIT1 : 1;
+  const int part = blockIdx.x % SPLIT;
+  if (P.build_beside) { ib = 0; jb = blockIdx.x / SPLIT; }      // block row 0 only: the rest is built beside diagonal block 0 (k_diag)
+  else tri_decode(blockIdx.x / SPLIT, ib, jb);
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD doubles
+  double* rowd = sm;
+  double* cold = sm + P.pre_slots * NB;
+  double* wl = cold + P.pre_slots * NB;
+  const double* pre = P.pre + b * P.sPre;
+  stage_factors(P, pre, ib, jb, rowd, cold);
+  if (threadIdx.x < P.q) wl[threadIdx.x] = P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + threadIdx.x];
+  __syncthreads();
+  double* A = P.A + b * P.sA;
+  const int c2 = (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
+  if (D == 1) {
+    build_part_1d<SPLIT>(P, rowd, cold, wl, b, ib, jb, part, threadIdx.x);
     return;
   }
   for (int rr = 0; rr < NB / 4; ++rr) {
@@ -568,7 +580,34 @@ __device__ __forceinline__ void early_inverse_tile(const PgmDev& P, double* lds,
   acc_store<C>(Rp, ld, acc, -1.0);
 }
 
-__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan, int nfill, int task_lo) {
+// Third filler role, diagonal block 0 only (one light curve, 1-D spectral mixture): while the first diagonal block is factored
+// nothing else of the sweep can run yet -- no block row is finished -- so the launch's other workgroups build the kernel matrix
+// below block row 0 (k_build built that row alone: all diagonal block 0 and row solve 0 need).  A workgroup takes whole tiles
+// (i, j), 1 <= i <= j, a quarter per 256 threads: the very code of k_build (build_part_1d), so the matrix has the same bits.
+__device__ __forceinline__ void build_beside_diag(const PgmDev& P, double* lds, int widx, int nworkers, int ntile) {
+  const int b = blockIdx.z;
+  double* rowd = lds;
+  double* cold = lds + P.pre_slots * NB;
+  double* wl = cold + P.pre_slots * NB;
+  const double* pre = P.pre + b * P.sPre;
+  if (threadIdx.x < P.q) wl[threadIdx.x] = P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + threadIdx.x];
+  const int total = P.pre_slots * NB;
+  for (int t = widx; t < ntile; t += nworkers) {
+    int i, j;
+    tri_decode(t, i, j);                                       // (triangle of the block rows 1 .. nb-1)
+    i += 1; j += 1;
+    for (int e = threadIdx.x; e < total; e += DIAG_THREADS) {
+      const int slot = e / NB, m = e % NB;
+      rowd[e] = pre[(int64_t)slot * P.np + i * NB + m];
+      cold[e] = pre[(int64_t)slot * P.np + j * NB + m];
+    }
+    __syncthreads();
+    build_part_1d<4>(P, rowd, cold, wl, b, i, j, (int)(threadIdx.x >> 8), (int)(threadIdx.x & 255));
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan, int nfill, int task_lo, int build_tiles) {
   const int b = blockIdx.z;
   // (no early exit on P.info here or in k_trsm / k_update: after a failed pivot the chain kernels just
   //  carry NaNs -- no address depends on data -- and a dependent scalar load in front of every one of the
@@ -585,6 +624,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   if (blockIdx.x > 0) {
     const int widx = (int)blockIdx.x - 1;
     if (widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, widx);
+    else if (build_tiles > 0) build_beside_diag(P, M, widx - nfill, (int)gridDim.x - 1 - nfill, build_tiles);   // (diagonal block 0 only)
     else early_inverse_tile(P, M, P.tasks[task_lo + widx - nfill]);
     return;
   }

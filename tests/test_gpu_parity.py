@@ -1274,7 +1274,7 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
     """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
     schedule and through the plainest one -- three-launch chain, eager plan of the update tiles (the default lets block rows
     fall two sources behind from 32 block rows on: n = 3970, the last fused size 5120, and inside the windows of 5130), whole-tile inverse pass, no
-    early inverse products: the same factor, hence the same value bit for bit; gradients to the rounding of their differently split sums; both against the
+    early inverse products, the whole matrix built before diagonal block 0 instead of beside it: the same factor, hence the same value bit for bit; gradients to the rounding of their differently split sums; both against the
     oracle where it is quick."""
     gen = torch.Generator().manual_seed(n)
     x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 1200)[0]
@@ -1282,7 +1282,7 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
     nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
     w = torch.tensor([0.7, 0.25], dtype=D); mu = torch.tensor([[0.013], [0.21]], dtype=D); v = torch.tensor([[0.004], [0.015]], dtype=D)
     outs = {}
-    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0"})):
+    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0", "PGM_BUILD_BESIDE": "0"})):
         _hip.release_workspaces()
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
