@@ -99,9 +99,11 @@ struct pgm_ws {
   // CUs; their spare workgroups form  R_ij = sum_p V_pi^T V_pj  over block rows p that are already final
   int lauum_sub_max;     // inverse/gradient pass: quarter-tile workgroups when a call has at most this many work items in all (0: never)
   int early;             // 0 = off
+  int early_t;           // early inverse-pass tasks also in the row-solve launches' idle CUs: most per launch (PGM_EARLY_T, 0: off)
   int early_nb;          // block rows the tables below were made for (-1: none)
   std::vector<int4> early_host;          // [final work items | filler tasks]
   std::vector<int> early_lo, early_n;    // filler tasks of diagonal-block launch k: [early_lo[k], +early_n[k]) of the task part
+  std::vector<int> early_lo_t, early_n_t; // the same for row-solve launch k (64x64 sub-tiles, four workgroups per task)
   int4* early_items;     // device copy
   int early_cap, early_final_n;
   double* Rbuf; size_t R_bytes;

@@ -563,13 +563,15 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
 // tile, they start on the inverse pass -- one product  R_ij += V_pi^T V_pj  of a block row p that is already final, kept
 // negated in R (acc_load_neg reads it back); k_lauum_grad later continues from R instead of from zero.
 constexpr int LAUUM_LOAD = 1 << 16;
-__device__ __forceinline__ void early_inverse_tile(const PgmDev& P, double* lds, const int4 task) {
-  using C = CfgFill;
+template <class C>
+__device__ __forceinline__ void early_inverse_tile(const PgmDev& P, double* lds, const int4 task, int sub = 0) {
+  constexpr int SUBN = NB / C::BN;
+  const int si = sub / SUBN, sj = sub % SUBN;                  // (64x64 sub-tiles when the task rides a row-solve launch)
   const int i = task.x, j = task.y, p = task.z;
   const int64_t ld = P.ld;
-  double* Rp = P.R + (int64_t)i * NB * ld + j * NB;
-  const double* pa0 = (p > i) ? P.A + (int64_t)p * NB * ld + i * NB : P.Dinv + ((int64_t)i * 2 + 1) * NB * NB;
-  const double* pb0 = (p > j) ? P.A + (int64_t)p * NB * ld + j * NB : P.Dinv + ((int64_t)j * 2 + 1) * NB * NB;
+  double* Rp = P.R + ((int64_t)i * NB + si * C::BM) * ld + j * NB + sj * C::BN;
+  const double* pa0 = ((p > i) ? P.A + (int64_t)p * NB * ld + i * NB : P.Dinv + ((int64_t)i * 2 + 1) * NB * NB) + si * C::BM;
+  const double* pb0 = ((p > j) ? P.A + (int64_t)p * NB * ld + j * NB : P.Dinv + ((int64_t)j * 2 + 1) * NB * NB) + sj * C::BN;
   const int64_t lda0 = (p > i) ? ld : NB, ldb0 = (p > j) ? ld : NB;
   v4d acc[C::TM][C::TN];
   const bool cont = (task.w & LAUUM_LOAD) != 0;
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
     const int widx = (int)blockIdx.x - 1;
     if (widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, widx);
     else if (build_tiles > 0) build_beside_diag(P, M, widx - nfill, (int)gridDim.x - 1 - nfill, build_tiles);   // (diagonal block 0 only)
-    else early_inverse_tile(P, M, P.tasks[task_lo + widx - nfill]);
+    else early_inverse_tile<CfgFill>(P, M, P.tasks[task_lo + widx - nfill]);
     return;
   }
   const int t = threadIdx.x, lane = t & 63;
@@ -915,14 +917,20 @@ __device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds
 }
 
 // workgroups [nlook, nlook + nslabs) are the row solve; the first nlook (0 or 36) form the next diagonal tile (look-ahead);
-// workgroups beyond are planned trailing-update tiles riding on this launch's idle CUs
-__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan, int nlook) {
+// workgroups beyond are planned trailing-update tiles riding on this launch's idle CUs, then early inverse-pass products
+// (64x64 sub-tiles of the tasks P.tasks[task_lo ...], four workgroups per task)
+__global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan, int nlook, int nextra, int task_lo) {
   using C = CfgTrsmChain;
   __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS];
   __shared__ double zs[NB];
   __shared__ double red[C::NT / 64][C::WN];
   if ((int)blockIdx.x < nlook) { lookahead_diag_tile<CfgLook>(P, lds, blockIdx.z, k, (int)blockIdx.x); return; }
   const int bx0 = (int)blockIdx.x - nlook;
+  if (bx0 >= nslabs + nextra) {                                  // early inverse-pass products on CUs the launch leaves idle (run_sweep)
+    const int e = bx0 - nslabs - nextra;
+    early_inverse_tile<CfgHead>(P, lds, P.tasks[task_lo + e / 4], e % 4);
+    return;
+  }
   if (bx0 >= nslabs) { plan_tile<CfgHead>(P, lds, plan, k_end, r_from, bx0 - nslabs); return; }
   int b = blockIdx.z, bx = bx0;
   if ((int)gridDim.x == nslabs) xcd_batch_remap(bx, b);          // (no planned tiles in the grid: batches, panel sweep)

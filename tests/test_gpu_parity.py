@@ -1282,7 +1282,7 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
     nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
     w = torch.tensor([0.7, 0.25], dtype=D); mu = torch.tensor([[0.013], [0.21]], dtype=D); v = torch.tensor([[0.004], [0.015]], dtype=D)
     outs = {}
-    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0", "PGM_BUILD_BESIDE": "0"})):
+    for name, env in (("default", {}), ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0", "PGM_BUILD_BESIDE": "0", "PGM_EARLY_T": "0"})):
         _hip.release_workspaces()
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
