@@ -1,0 +1,61 @@
+"""Random light curves through the HIP path (C ABI) and the CPU oracle: lengths around every schedule boundary (one tile,
+32 tiles = where the build moves beside diagonal block 0, 8 block rows = where the early inverse pass starts, the quarter-tile
+inverse pass, ragged last blocks), 1..4 mixture components, 1-D and 2-D inputs in both dimension orders, fixed-noise vector
+and/or learned scalar noise, value + every gradient.  PGM_FUZZ_CASES / PGM_FUZZ_SEED widen the run (profiles/r02_fuzz_parity.txt:
+168 cases)."""
+import os
+
+import pytest
+import torch
+
+from pgmuvi_amd import _hip
+from oracle import sm_mll_oracle as orc
+
+pytestmark = pytest.mark.gpu
+D = torch.float64
+SIZES = [17, 89, 127, 128, 129, 255, 257, 383, 511, 640, 897, 1000, 1023, 1024, 1025, 1100, 1153, 1280, 1409, 1537]
+
+
+def test_random_light_curves_against_the_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("-m gpu tests need the MI355X")
+    dev = torch.device("cuda:0")
+    cases = int(os.environ.get("PGM_FUZZ_CASES", "36"))
+    gen = torch.Generator().manual_seed(int(os.environ.get("PGM_FUZZ_SEED", "20261004")))
+    worst_v, worst_g, report = 0.0, 0.0, []
+    for c in range(cases):
+        n = SIZES[int(torch.randint(len(SIZES), (1,), generator=gen))] if c % 3 else int(torch.randint(20, 1500, (1,), generator=gen))
+        q = int(torch.randint(1, 5, (1,), generator=gen)); d = 1 if c % 4 else 2
+        order = int(torch.randint(2, (1,), generator=gen)) if d == 2 else 0
+        x = torch.rand(n, d, generator=gen, dtype=D) * 800.0
+        if d == 1:
+            x = torch.sort(x[:, 0])[0].reshape(n, 1)
+        else:
+            x[:, 1] = torch.randint(1, 4, (n,), generator=gen).double() * 0.5
+        y = torch.randn(n, generator=gen, dtype=D)
+        use_vec = c % 5 != 0
+        noise = (0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)) if use_vec else None
+        ns = None if (use_vec and c % 2) else float(0.02 + 0.1 * torch.rand(1, generator=gen))
+        w = 0.1 + torch.rand(q, generator=gen, dtype=D)
+        mu = 0.005 + 0.3 * torch.rand(q, d, generator=gen, dtype=D)
+        v = 0.001 + 0.02 * torch.rand(q, d, generator=gen, dtype=D)
+        mean = float(torch.randn(1, generator=gen)) * 0.3
+        out = _hip.mll_value_grad(x.to(dev), y.to(dev), torch.full((n,), mean, dtype=D, device=dev), None if noise is None else noise.to(dev),
+                                  None if ns is None else torch.tensor(ns, dtype=D, device=dev), w.to(dev), mu.to(dev), v.to(dev), order, 0.0, True)
+        torch.cuda.synchronize()
+        total = (noise if noise is not None else torch.zeros(n, dtype=D)) + (0.0 if ns is None else ns)
+        val, gr = orc.mll_value_grad_closed_form(x if d == 2 else x[:, 0], y, mean, total, w, mu, v, order, 0.0)
+        dv = abs(float(out["mll"]) - float(val))
+        dg = 0.0
+        for p in ("w", "mu", "v", "mean", "noise"):
+            a, b = out[f"g_{p}"].detach().cpu().double().reshape(-1), gr[p].reshape(-1).double()
+            dg = max(dg, float((a - b).abs().max() / (b.abs().max() + 1e-300)))
+        line = (f"case {c:3d}: n={n:5d} q={q} d={d} order={order} noise={'vector' if use_vec else 'none'}{'+scalar' if ns is not None else ''}: "
+                f"|d mll| {dv:.2e}  grad rel {dg:.2e}")
+        print(line, flush=True)
+        if not (int(out["info"]) == 0 and dv < 1e-9 and dg < 1e-7):
+            report.append(line)
+        worst_v, worst_g = max(worst_v, dv), max(worst_g, dg)
+        _hip.release_workspaces()
+    print(f"{cases} cases: worst |d mll| {worst_v:.2e}, worst gradient deviation {worst_g:.2e}, {len(report)} outside tolerance")
+    assert not report, report
