@@ -231,11 +231,14 @@ int main() {
       hipMemset(Acold, 0, sizeof(double) * ld * rows);
       using F16p4 = TileCfg<128, 128, 32, 32, 4, 1024, 16>;
       using Big4 = TileCfg<128, 128, 64, 64, 4>;
-      for (int nkb : {2, 4}) {
+      for (int nkb : {2, 4, 16}) {
         run_cold<F16, 4>("COLD operands, 16 waves 32x32/wave PF2, 1 WG/CU", Acold, ld, rows, out, 255, nkb);
         run_cold<F16p4, 4>("COLD operands, 16 waves 32x32/wave PF4, 1 WG/CU", Acold, ld, rows, out, 255, nkb);
         run_cold<Big, 2>("COLD operands, 4 waves 64x64/wave PF2, 2 WG/CU", Acold, ld, rows, out, 510, nkb);
         run_cold<Big4, 2>("COLD operands, 4 waves 64x64/wave PF4, 2 WG/CU", Acold, ld, rows, out, 510, nkb);
+        // the same with a row pitch that is not a power of two (4096 + 16 doubles): do the 32-KB-strided rows of a panel collide?
+        run_cold<Big, 2>("COLD operands, 4 waves 64x64/wave PF2, 2 WG/CU, pitch 4112", Acold, ld + 16, rows - 256, out, 510, nkb);
+        run_cold<F16, 4>("COLD operands, 16 waves 32x32/wave PF2, 1 WG/CU, pitch 4112", Acold, ld + 16, rows - 256, out, 255, nkb);
       }
       hipFree(Acold);
     }
