@@ -15,6 +15,13 @@ int main() {
                          "16 waves 128x128, PF2, C tile negated late", "4 waves 128x128 (64x64 each), 2/CU, C tile negated late",
                          "8 waves 64x64 sub-tiles, C tile negated late", "16 waves 128x128, PF2, 32-row chunks, negated late",
                          "16 waves 128x128, PF4, 16-row chunks, negated late", "16 waves 128x128, PF4, 8-row chunks, negated late"};
+  // fewer tiles than CUs: is the C tile's round trip a matter of how many workgroups ask at once?
+  for (int tiles : {16, 32, 64, 128, 192, 255})
+    for (int nkb : {1, 2}) {
+      double us = 0.0;
+      const int rc = pgm_debug_tile_probe(ws, 10, tiles, nkb, 20, &us);
+      printf("%-58s tiles %3d nkb %d: %7.2f us per launch%s\n", "16 waves 128x128, PF2, negated late, partly filled chip", tiles, nkb, us, rc ? "  (FAILED)" : "");
+    }
   for (int cfg = 0; cfg < 16; ++cfg)
     for (int tiles : {255, 510})
       for (int nkb : {1, 2}) {
