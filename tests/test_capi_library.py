@@ -124,7 +124,9 @@ def test_sweep_plans_are_valid_for_every_shape():
     kernels' tile decode on a table of 'next source this tile expects'.  Valid = every tile receives the finished block rows in
     ascending order, none twice, none skipped (a row three behind would silently lose a source: the kernels apply at most two
     per pass); every block row is complete when its diagonal block / row solve starts; the look-ahead finds its copy of tile
-    (k, k+1) and an up-to-date diagonal tile (k+1, k+1) and never shares a launch with tail tiles of that row.  All block-row
+    (k, k+1) and an up-to-date diagonal tile (k+1, k+1) and never shares a launch with tail tiles of that row; the early
+    inverse pass's tasks (one light curve with gradient) take each tile's products in ascending order from block rows that are
+    final, never the same tile twice in one launch, and leave the final pass exactly the rest.  All block-row
     counts up to 64 (N = 8192), batch sizes, value-only, look-ahead on / off / switched in mid-sweep, lazy / eager plan,
     fused / panels / windowed."""
     f = _plan_check()
@@ -153,3 +155,10 @@ def test_the_plan_check_notices_a_damaged_plan():
         assert f(nb, 1, 1, 0, 1, -1, -1, 0, 1) > 0
         assert f(nb, 1, 1, 0, 1, -1, -1, 0, 2) > 0
     assert f(8, 1, 1, 0, 1, -1, -1, 0, 1) == 0                  # (every row fits every launch: nothing lazy to damage)
+    # the early inverse pass's task tables (one light curve with gradient, 8 block rows and more) ride in the same check:
+    # damaged so that a tile may be taken twice in one launch (read-modify-write of R within a launch), it must notice
+    # (up to ~24 block rows every launch has room for all the products that are ready, a tile never has two of them
+    #  waiting, and the damage cannot show)
+    for nb in (8, 16, 32, 40, 48):
+        assert f(nb, 1, 1, 0, 1, -1, -1, 0, 0) == 0
+        assert (f(nb, 1, 1, 0, 1, -1, -1, 0, 3) > 0) == (nb >= 32)
