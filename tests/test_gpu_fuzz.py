@@ -59,3 +59,36 @@ def test_random_light_curves_against_the_oracle():
         _hip.release_workspaces()
     print(f"{cases} cases: worst |d mll| {worst_v:.2e}, worst gradient deviation {worst_g:.2e}, {len(report)} outside tolerance")
     assert not report, report
+
+
+@pytest.mark.parametrize("case", ["duplicate_times", "noise_over_eight_decades", "constant_series", "one_dominant_component"])
+def test_collisions_and_extremes_against_the_oracle(case):
+    """Inputs the reference's own tests worry about: repeated observation times (two rows of K identical up to the noise),
+    noise variances from 1e-6 to 1e2 in one light curve, a constant series, one mixture weight dwarfing the others."""
+    if not torch.cuda.is_available():
+        pytest.skip("-m gpu tests need the MI355X")
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(len(case))
+    n = 700
+    x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 400.0)[0]
+    y = torch.randn(n, generator=gen, dtype=D)
+    noise = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+    w = torch.tensor([0.6, 0.3, 0.2], dtype=D); mu = torch.tensor([[0.02], [0.11], [0.3]], dtype=D); v = torch.tensor([[0.003], [0.01], [0.02]], dtype=D)
+    if case == "duplicate_times":
+        x[100:200] = x[300:400]                                 # 100 exact collisions (unsorted on purpose: order is free)
+    elif case == "noise_over_eight_decades":
+        noise = 10.0 ** (-6.0 + 8.0 * torch.rand(n, generator=gen, dtype=D))
+    elif case == "constant_series":
+        y = torch.full((n,), 3.25, dtype=D)
+    elif case == "one_dominant_component":
+        w = torch.tensor([50.0, 1e-6, 1e-3], dtype=D)
+    out = _hip.mll_value_grad(x.reshape(n, 1).to(dev), y.to(dev), torch.full((n,), 0.4, dtype=D, device=dev), noise.to(dev), None,
+                              w.to(dev), mu.to(dev), v.to(dev), 0, 0.0, True)
+    torch.cuda.synchronize()
+    val, gr = orc.mll_value_grad_closed_form(x, y, 0.4, noise, w, mu, v, 0, 0.0)
+    assert int(out["info"]) == 0
+    assert abs(float(out["mll"]) - float(val)) < 1e-9 * max(1.0, abs(float(val)))
+    for p in ("w", "mu", "v", "mean", "noise"):
+        a, b = out[f"g_{p}"].detach().cpu().double().reshape(-1), gr[p].reshape(-1).double()
+        assert float((a - b).abs().max() / (b.abs().max() + 1e-300)) < 1e-7, (case, p)
+    _hip.release_workspaces()
