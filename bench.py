@@ -5,6 +5,11 @@
     python bench.py --gpus N --steps K --warmup W --total-batch B [--npoints 2048] # strong scaling of one B-light-curve batch
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher and with ``--gpus N`` > 1 the process is only a parent: before anything touches a GPU it starts N
+fresh children of its own command line, one rank per GPU (``pgmuvi_amd.launch.spawn_ranks``: RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* as torch.distributed.run sets them), relays rank 0's JSON line and exits with the children's worst status; with fewer
+than N visible devices it exits non-zero with a one-line reason.
+
 A *step* is one pass of the hot path -- SM kernel build + blocked Cholesky MLL + full
 hyper-parameter gradient (pgmuvi/trainers.py:179-181 without the optimiser step) -- over
 one batch of B synthetic config-2 light curves per GPU (N=4096 points, Q=4 mixtures,
@@ -34,7 +39,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pgmuvi_amd import _hip, synthetic as syn  # noqa: E402
+from pgmuvi_amd import _hip, launch, synthetic as syn  # noqa: E402
 from pgmuvi_amd.batch import default_chunk, gather_logliks, make_shard, sharded_batch_step, shard_bounds  # noqa: E402
 
 PMC_GLOB = "r*_pmc_hbm_traffic*.json"   # tools/pmc_traffic.py output; only a file measured on the CURRENT library is quoted
@@ -116,7 +121,8 @@ def cpu_baseline(n, reps, recipe="cfg2"):
     med = times[len(times) // 2]
     return dict(value=1.0 / med, unit="evals/s", cores=torch.get_num_threads(), kind="port", cpu_model=_cpu_model(),
                 sample=f"{reps} value+grad evaluations (1 warm-up) of {what}, median {med * 1e3:.0f} ms; torch-CPU restatement of the "
-                       "reference path (oracle/), not GPyTorch"), float(val)
+                       f"reference path (oracle/), not GPyTorch; torch threads capped at 16 = one GPU's share of the host "
+                       f"({os.cpu_count()} logical CPUs on the box)"), float(val)
 
 
 def lib_sha16():
@@ -188,23 +194,55 @@ def sweep_roofline(prof, ws, n, nloc, steps):
     return roofline
 
 
-def build_roofline(prof, n, nloc):
-    """The HBM-bound stage of the path: the kernel build streams the upper block triangle of A out once (8 N^2 / 2 bytes at
-    tile granularity; it is in fact bound by the Q N^2 / 2 fp64 exp it evaluates).  For one light curve with
-    more than 32 tiles the `sm_build` phase is block row 0 only: the library builds the rest beside diagonal block 0, inside
-    the first k_diag launch, where it cannot be timed apart -- the line then says so."""
+EXP_PAIR_INSTRS = 27      # fp64 VALU instructions per (pair, mixture) of the 1-D build: 20 of them the branch-free exp
+
+
+def build_roofline(prof, n, nloc, q=4, beside=False):
+    """The HBM-bound stage of the path: the kernel build streams the upper block triangle of A out
+    once -- 8 N^2 / 2 bytes at tile granularity -- from ``prof`` = per-launch HIP-event times of a run in which the WHOLE
+    matrix is built by k_build (``whole_build_profile``).  Beside the achieved GB/s stands the floor the Q N^2 / 2 fp64 exp
+    set (VALU issue: the build is bound by them, not by HBM)."""
     nbk = (n + NB - 1) // NB
     build_ms, build_launches = prof["sm_build"]
     ntiles = nbk * (nbk + 1) // 2
-    beside = nloc == 1 and ntiles > 32 and os.environ.get("PGM_BUILD_BESIDE", "1") != "0"
-    build_bytes = 8.0 * NB * NB * (nbk if beside else ntiles) * nloc
-    gbs = build_bytes * build_launches / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
-    kernel = ("k_build (spectral-mixture kernel matrix, block row 0 only: a short, latency-bound launch; the other "
-              f"{ntiles - nbk} tiles are built by the spare workgroups of the first k_diag launch)" if beside
-              else "k_build (spectral-mixture kernel matrix, upper block triangle)")
-    return dict(bound="hbm", kernel=kernel, achieved=round(gbs, 1),
-                peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4), avg_launch_us=round(build_ms / max(build_launches, 1) * 1e3, 2),
-                bytes_per_launch=build_bytes)
+    build_bytes = 8.0 * NB * NB * ntiles * nloc
+    us = build_ms / max(build_launches, 1) * 1e3
+    gbs = build_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    # 256 CUs x 4 SIMDs x 16 fp64 lanes per clock at 2.4 GHz
+    exp_floor_us = ntiles * nloc * NB * NB * q * EXP_PAIR_INSTRS / (256 * 4 * 16 * 2.4e3)
+    kernel = "k_build (spectral-mixture kernel matrix, upper block triangle, one launch)"
+    if beside:
+        kernel += ("; timed on a side workspace with PGM_BUILD_BESIDE=0, outside the timed region -- in the production path of one "
+                   "light curve only block row 0 is a launch of its own, the other tiles are built by the spare workgroups of "
+                   "the first k_diag launch, hidden beside diagonal block 0")
+    return dict(bound="hbm", kernel=kernel, achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
+                avg_launch_us=round(us, 2), bytes_per_launch=build_bytes,
+                exp_issue_floor_us=round(exp_floor_us, 2), frac_of_exp_issue_floor=round(exp_floor_us / us, 4) if us > 0 else None)
+
+
+def whole_build_profile(dev, data, n, reps=5):
+    """Per-launch times of ``reps`` value-only evaluations of one light curve on a workspace created with
+    PGM_BUILD_BESIDE=0 (the switch is read when a workspace is made): there the whole matrix is one k_build launch."""
+    prev = os.environ.get("PGM_BUILD_BESIDE")
+    os.environ["PGM_BUILD_BESIDE"] = "0"
+    try:
+        side = _hip.Workspace(dev, (n + NB - 1) // NB * NB, 4, 1, 1)
+    finally:
+        if prev is None:
+            os.environ.pop("PGM_BUILD_BESIDE", None)
+        else:
+            os.environ["PGM_BUILD_BESIDE"] = prev
+    one = {k: v[0] for k, v in data.items()}
+    f = lambda: _hip.mll_value_grad(one["x"], one["y"], one["mean"], one["noise"], None, one["w"], one["mu"], one["v"], 0, 0.0, False,
+                                    workspace=side)
+    f(); torch.cuda.synchronize()
+    side.profile(True)
+    for _ in range(reps):
+        f()
+    prof = side.profile_read()
+    side.profile(False)
+    side.close()
+    return prof
 
 
 class Harness:
@@ -278,23 +316,30 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the batched / strong-scaling side measurements")
+    ap.add_argument("--no-big-batch", action="store_true", help="skip the 4096 x N=4096 strong-scaling side measurement (about 16 s on one GPU)")
+    ap.add_argument("--spawn", action="store_true", help="go through the self-launcher even with --gpus 1 (a one-rank RCCL job)")
     args = ap.parse_args()
 
+    if not launch.under_a_launcher() and (args.gpus > 1 or args.spawn):
+        # parent only: nothing here has touched (or will touch) a GPU -- device_count() does not initialise HIP
+        sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                    visible_devices=torch.cuda.device_count()))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it plainly, or with --nproc-per-node {args.gpus})")
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} needs GPU {local}, {torch.cuda.device_count()} visible (there is no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # (PGM_BENCH_DIST=1: initialise RCCL even for a single rank -- lets a one-GPU box exercise the collective path)
-    if world > 1 or os.environ.get("PGM_BENCH_DIST") == "1":
+    # one rank per GPU over RCCL ("nccl" is RCCL on ROCm) whenever a launcher made this process a rank -- also a job of one
+    # rank, which lets a one-GPU box exercise the collective path (--spawn; PGM_BENCH_DIST=1 does the same without a launcher)
+    if launch.under_a_launcher() or os.environ.get("PGM_BENCH_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     h = Harness(dev, world)
     n = args.n
     metric = "marginal-log-likelihood evals/sec, N=4096 Q=4 SM kernel" if n == 4096 else f"marginal-log-likelihood evals/sec, N={n} Q=4 SM kernel"
@@ -317,7 +362,7 @@ def main():
             }
             if prof is not None:                                  # one profiled pass of rank 0's shard
                 result["roofline"] = sweep_roofline(prof, ws, n, nloc, 1)
-                result["roofline_build"] = build_roofline(prof, n, min(nloc, res["chunk"]))
+                result["roofline_build"] = build_roofline(prof, n, min(nloc, res["chunk"]))     # (batches build the whole matrix in k_build)
                 result["phase_ms_per_step"] = {k: round(v[0], 4) for k, v in prof.items()}
             if world == 1 and not args.no_cpu:
                 cb, cpu_val = cpu_baseline(n, args.cpu_reps, "cfg3")
@@ -345,6 +390,7 @@ def main():
     assert ll.numel() == B * world and bool(torch.isfinite(ll).all())
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+    gpu_val = float(out["mll"].reshape(-1)[0])
 
     # ---- per-kernel device time (HIP events on the launch stream), same K steps again
     ws.profile(True)
@@ -353,7 +399,11 @@ def main():
     prof = ws.profile_read()
     ws.profile(False)
     roofline = sweep_roofline(prof, ws, n, B, args.steps)
-    roofline_build = build_roofline(prof, n, B)
+    nbk = (n + NB - 1) // NB
+    beside = B == 1 and nbk * (nbk + 1) // 2 > 32 and os.environ.get("PGM_BUILD_BESIDE", "1") != "0"
+    # the HBM-bound stage, whole: where the production path hides most of the build inside the first k_diag launch it is
+    # timed once on a side workspace that builds the matrix in one launch (outside the timed region)
+    roofline_build = build_roofline(whole_build_profile(dev, data, n) if beside else prof, n, 1 if beside else B, beside=beside)
     phases = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
 
     result = None
@@ -370,6 +420,12 @@ def main():
             "roofline_build": roofline_build,
             "phase_ms_per_step": phases,
         }
+        if world > 1:
+            result["note"] = ("weak scaling of ONE light curve per GPU: a step is a ~2 ms evaluation followed by a blocking all_gather with "
+                              "nothing to overlap it, so the N>1 values of this line measure collective latency per step; the batch "
+                              "measurement in `strong_scaling` is the meaningful multi-GPU figure (north_star: 4096-light-curve batch)")
+            result["cpu_baseline"] = None
+            result["cpu_baseline_note"] = "timed on rank 0 of the N=1 run only (the contract's rule); see that run's line"
     extra = {}
     if world == 1 and not args.no_extra:
         # measured fp64 MFMA issue rate on this device (context for the datasheet peak)
@@ -398,15 +454,22 @@ def main():
         del d2, ws2
     if not args.no_extra:
         # strong scaling beside the headline (at every world size, so that the driver's N=1,2,4,8 runs record it): BASELINE
-        # configs[2] (512 x N=2048) and the north_star's 4096-light-curve batch at the headline size; the whole batch per step
+        # configs[2] (512 x N=2048) and the north_star's 4096-light-curve batch at the headline size; the whole batch per step.
+        # The headline's workspaces go first (the batches bring their own, 8.6 GB for 64 x N=4096).
+        del ws, data, out, ll, step
+        _hip.release_workspaces()
+        torch.cuda.empty_cache()
         ss = {}
-        for tag, total, nn, k, w in (("cfg3_512_x_n2048", 512, 2048, 3, 1), ("batch4096_x_n4096", 4096, 4096, 1, 0)):
+        cases = [("cfg3_512_x_n2048", 512, 2048, 3, 1)]
+        if not args.no_big_batch:
+            cases.append(("batch4096_x_n4096", 4096, 4096, 2, 1))
+        for tag, total, nn, k, w in cases:
             ss[tag] = strong_scaling_run(h, total, nn, k, w, rank, world, dev, None, profile=False)[0]
+            _hip.release_workspaces()
         extra["strong_scaling"] = ss
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, cpu_val = cpu_baseline(n, args.cpu_reps)
         result["cpu_baseline"] = cb
-        gpu_val = float(out["mll"].reshape(-1)[0])
         result["parity"] = {"abs_dmll_vs_cpu_oracle": abs(gpu_val - cpu_val), "tolerance": 1e-4, "mll": gpu_val}
         result["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
     if rank == 0:

@@ -201,6 +201,14 @@ int pgm_lomb_scargle_f64(const double* t, const double* y, const double* dy, int
  * capture of the caller).
  */
 int pgm_factorisation_status(pgm_ws* ws, int* info_host, int batch);
+/*
+ * The same for one particular evaluation: pgm_last_evaluation(ws) right after a call names the evaluation that call enqueued
+ * (a counter per workspace); pgm_factorisation_status_of returns -1 when another evaluation has been enqueued on `ws`
+ * since -- the host-visible status then belongs to that one, and the caller falls back to the `info` array its own call
+ * filled on the device.  (A workspace is shared by every request it covers: a second model, a chunk of a batch.)
+ */
+int64_t pgm_last_evaluation(const pgm_ws* ws);
+int pgm_factorisation_status_of(pgm_ws* ws, int64_t evaluation, int* info_host, int batch);
 
 /*
  * The reference's other exact-GP models (pgmuvi/gps.py:915-1342: QuasiPeriodicGPModel, MaternGPModel,

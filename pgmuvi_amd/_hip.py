@@ -26,6 +26,8 @@ SYMBOLS = {
     "pgm_workspace_destroy": (c_int, [c_void_p]),
     "pgm_workspace_bytes": (c_size_t, [c_void_p]),
     "pgm_factorisation_status": (c_int, [c_void_p, c_void_p, c_int]),
+    "pgm_last_evaluation": (c_int64, [c_void_p]),
+    "pgm_factorisation_status_of": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
     "pgm_sm_kernel_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_double, c_int, c_void_p, c_int64, c_void_p]),
     "pgm_mll_value_grad_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int,
@@ -149,12 +151,17 @@ class Workspace:
         except Exception:
             pass
 
-    def factorisation_failed(self, batch: int = 1):
-        """Did any of the ``batch`` problems of the last evaluation on this workspace fail to factor?  Waits for the event the
-        library records after the factorisation sweep only -- the inverse/gradient pass keeps running behind it -- so the caller's
-        host work overlaps the rest of the evaluation (pgm_factorisation_status).  None when nothing was published (the
-        evaluation ran inside a stream capture): the caller then reads ``info`` from the device."""
-        rc = load().pgm_factorisation_status(self.handle, None, int(batch))
+    def last_evaluation(self) -> int:
+        """Number of the evaluation enqueued last on this workspace (the stamp ``factorisation_failed`` takes)."""
+        return int(load().pgm_last_evaluation(self.handle))
+
+    def factorisation_failed(self, batch: int = 1, evaluation: int = -1):
+        """Did any of the ``batch`` problems of evaluation number ``evaluation`` (-1: the last one) on this workspace fail to
+        factor?  Waits for the event the library records after the factorisation sweep only -- the inverse/gradient pass keeps
+        running behind it -- so the caller's host work overlaps the rest of the evaluation (pgm_factorisation_status_of).
+        None when there is nothing to report for THAT evaluation (it ran inside a stream capture, or another evaluation has
+        been enqueued on the workspace since): the caller then reads its own ``info`` from the device."""
+        rc = load().pgm_factorisation_status_of(self.handle, int(evaluation), None, int(batch))
         if rc < 0:
             return None
         return rc > 0
@@ -177,7 +184,7 @@ class Workspace:
 
 
 # Cache of workspaces, least recently used first.  A request is served by ANY cached workspace that covers it (the C side
-# takes n <= max_n, q d <= max_q max_d, d <= max_d, batch <= max_batch), the smallest such; a miss allocates an exact fit and
+# takes n <= max_n, q <= max_q, d <= max_d, batch <= max_batch), the smallest such; a miss allocates an exact fit and
 # then drops least-recently-used entries from the cache until it is back under the byte budget.  Dropping never frees: the
 # device buffers go when the last holder lets go of the Workspace object (a NativeFit, the dictionary an evaluation
 # returned, a captured graph's owner ...), so raw addresses baked into graphs and handles stay valid for as long as
@@ -188,8 +195,10 @@ WORKSPACE_BUDGET_BYTES = int(float(os.environ.get("PGMUVI_WORKSPACE_BUDGET_GB", 
 
 
 def _covers(ws: "Workspace", idx: int, np_: int, q: int, d: int, batch: int) -> bool:
-    return (ws.handle is not None and ws.key[0] == idx and ws.max_n >= np_ and ws.max_d >= d and ws.max_q * ws.max_d >= q * d
-            and ws.max_batch >= batch)
+    # (max_q >= q as well as the product: the per-work-item partial sums are strided by q + 2 q d + 1 slots, which a
+    #  (q=8, d=1) request would overrun in a workspace made for (q=4, d=2) although q d fits)
+    return (ws.handle is not None and ws.key[0] == idx and ws.max_n >= np_ and ws.max_d >= d and ws.max_q >= q
+            and ws.max_q * ws.max_d >= q * d and ws.max_batch >= batch)
 
 
 def get_workspace(device, n: int, q: int, d: int, batch: int = 1) -> Workspace:
@@ -217,6 +226,14 @@ def get_workspace(device, n: int, q: int, d: int, batch: int = 1) -> Workspace:
                 continue
             total -= _workspaces.pop(key).nominal_bytes  # (freed when its last holder drops it)
         return ws
+
+
+def cached_workspaces(device=None):
+    """The Workspace objects in the cache (of one device): whoever replays a captured graph that has workspace addresses
+    baked in holds this list for as long as the graph lives."""
+    with _ws_lock:
+        idx = None if device is None else (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+        return [w for w in _workspaces.values() if idx is None or w.key[0] == idx]
 
 
 def release_workspaces():
@@ -350,6 +367,7 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
     out["_buf"], out["_offs"] = buf, offs                    # (one contiguous buffer: a caller can scale every gradient with one multiply)
     out["workspace"] = ws
+    out["evaluation"] = ws.last_evaluation()
     return out
 
 
@@ -408,6 +426,7 @@ def mll_kernel_value_grad(x, y, mean, noise, noise_scalar, program, theta, jitte
     out["_keep"] = (xd, yd, md, nz, ns, th)
     out["mll"], out["info"] = out["mll"][0], out["info"][0]
     out["workspace"] = ws
+    out["evaluation"] = ws.last_evaluation()
     return out
 
 

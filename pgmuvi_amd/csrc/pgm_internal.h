@@ -116,6 +116,7 @@ struct pgm_ws {
   int* info_host;        // host-mapped pinned copy of `info`, written by the last diagonal-block launch of the sweep
   int* info_host_dev;    // its device address
   int status_batch;      // problems of the last evaluation that published a status (0: none, or inside a caller's capture)
+  int64_t eval_seq;      // evaluations run on this workspace so far: the status belongs to evaluation number eval_seq (pgm_last_evaluation)
   std::vector<GraphEntry> graphs;
   // profiling
   bool prof_on;

@@ -1,0 +1,112 @@
+"""One process per GPU without an external launcher.
+
+``python bench.py --gpus N`` (N > 1) must work as the driver types it.  The process that
+was started is then only a *parent*: before anything touches the GPU it starts N fresh
+children of the same command line -- one per rank, with ``RANK`` / ``LOCAL_RANK`` /
+``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT`` in their environment, exactly what
+``python -m torch.distributed.run`` would have set -- relays rank 0's standard output
+(the one JSON line) and returns the worst exit status of the children.  No process that
+has initialised the GPU is ever replaced by another program (that takes the whole
+machine down on this pool): children are started with ``subprocess.Popen``.
+
+Nothing here imports torch; the caller passes the number of visible devices (counted with
+``torch.cuda.device_count()``, which does not initialise HIP on this image).
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+from typing import Dict, List, Optional, Sequence
+
+CHILD_MARK = "PGM_LAUNCH_CHILD"
+
+
+def under_a_launcher(env=None) -> bool:
+    """Has somebody (torch.distributed.run, or :func:`spawn_ranks`) already made this process one rank of a job?"""
+    env = os.environ if env is None else env
+    return "WORLD_SIZE" in env and "RANK" in env
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_environment(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
+    """Environment of rank ``rank`` of a one-node job of ``world`` ranks (one rank per GPU: LOCAL_RANK == RANK)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver only supports dmabuf IPC (RCCL needs it)
+    env[CHILD_MARK] = "1"
+    return env
+
+
+def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] = None, grace_s: float = 15.0,
+                out=None, err=None) -> int:
+    """Runs ``argv`` (a full command line, e.g. ``[sys.executable, "bench.py", "--gpus", "4", ...]``) once per rank and
+    waits.  Rank 0's stdout is relayed line by line to ``out`` (default: this process's stdout); the other ranks' stdout goes
+    to ``err`` with everybody's stderr.  Returns 0 when every rank returned 0, otherwise the first non-zero status seen (a
+    rank that fails takes the others down after ``grace_s`` seconds: they would wait in a collective for ever).
+    ``visible_devices``: refuse (status 2, one line on ``err``) when fewer devices than ranks are visible; None = no check
+    (CPU jobs on gloo)."""
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    if world < 1:
+        print(f"launch: {world} ranks requested", file=err)
+        return 2
+    if visible_devices is not None and visible_devices < world:
+        print(f"launch: --gpus {world} needs {world} visible GPUs, this host shows {visible_devices}", file=err)
+        return 2
+    port = free_port()
+    procs: List[subprocess.Popen] = []
+    try:
+        child_err = err.fileno()                               # (a real descriptor: the children write to it directly)
+    except (AttributeError, OSError, ValueError):
+        child_err = None                                       # inherit this process's stderr
+    try:
+        for r in range(world):
+            procs.append(subprocess.Popen(list(argv), env=rank_environment(r, world, port),
+                                          stdout=subprocess.PIPE if r == 0 else (child_err if child_err is not None else 2),
+                                          stderr=child_err, text=(r == 0)))
+        # rank 0's lines are relayed as they come (it prints little: the JSON line at the end) by a reader thread, so that
+        # this thread keeps watching every rank: one that dies early leaves the others waiting in a collective
+        def relay():
+            for line in procs[0].stdout:
+                out.write(line)
+                out.flush()
+        reader = threading.Thread(target=relay, daemon=True)
+        reader.start()
+        status, failed_at = 0, None
+        pending = set(range(world))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0 and status == 0:
+                    status, failed_at = rc, time.monotonic()
+                    print(f"launch: rank {r} exited with status {rc}", file=err)
+            if pending and failed_at is not None and time.monotonic() - failed_at > grace_s:
+                for r in pending:                                # (exactly the processes started above, by handle)
+                    procs[r].terminate()
+                failed_at = time.monotonic() + 1e9
+            if pending:
+                time.sleep(0.05)
+        reader.join(timeout=10)
+        return status if status >= 0 else 128 - status             # (killed by a signal: the shell's convention)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass

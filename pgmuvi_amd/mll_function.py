@@ -24,7 +24,7 @@ def _failed(out) -> bool:
     overlaps the rest of the evaluation."""
     ws = out.get("workspace")
     info = out["info"]
-    status = ws.factorisation_failed(info.numel()) if hasattr(ws, "factorisation_failed") else None
+    status = ws.factorisation_failed(info.numel(), out.get("evaluation", -1)) if hasattr(ws, "factorisation_failed") else None
     return bool((info != 0).any()) if status is None else status
 
 

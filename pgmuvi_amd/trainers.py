@@ -23,86 +23,110 @@ def _iterate(n, progress):
     return range(n)
 
 
+# ---- the pieces all three loops share (what the reference's ``train`` does around its loop body, ``trainers.py:82-209``) ----
+def _problem(lightcurve, model, likelihood, train_x, train_y):
+    """(model, likelihood, x, y) from a Lightcurve or from the four loose arguments (all of them, or ValueError)."""
+    loose = (model, likelihood, train_x, train_y)
+    if lightcurve is not None:
+        if any(v is not None for v in loose):
+            print("train(): a lightcurve was given together with model / likelihood / train_x / train_y; "
+                  "the lightcurve is used and the loose arguments are ignored.")
+        return lightcurve.model, lightcurve.likelihood, lightcurve._xdata_transformed, lightcurve._ydata_transformed
+    if any(v is None for v in loose):
+        raise ValueError("train() without a lightcurve needs all of model, likelihood, train_x and train_y.")
+    return loose
+
+
+def _mll_objective(lossfn, likelihood, model):
+    """Only the exact marginal log-likelihood is trainable (as in the reference): "mll" -> the shim's
+    ExactMarginalLogLikelihood; "elbo" and ready-made MLL objects -> NotImplementedError; anything else -> ValueError."""
+    if lossfn == "mll":
+        return gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    if lossfn == "elbo" or isinstance(lossfn, gpytorch.mlls.marginal_log_likelihood.MarginalLogLikelihood):
+        raise NotImplementedError("only lossfn='mll' (exact marginal log-likelihood) is implemented")
+    raise ValueError("lossfn must be 'mll' ('elbo' and MLL objects are not implemented yet)")
+
+
+_OPTIMISERS = {
+    "SGD": lambda params, lr, eps, **kw: torch.optim.SGD(params, lr=lr),
+    "Adam": lambda params, lr, eps, **kw: torch.optim.Adam(params, lr=lr, eps=eps, **kw),
+    "AdamW": lambda params, lr, eps, **kw: torch.optim.AdamW(params, lr=lr, eps=eps, **kw),
+}
+
+
+def _optimiser(optim, params, lr, eps, instances=True, **kw):
+    if isinstance(optim, str) and optim in _OPTIMISERS:
+        return _OPTIMISERS[optim](params, lr, eps, **kw)
+    if optim == "NUTS":
+        raise NotImplementedError("optim='NUTS': sampling is pgmuvi_amd.mcmc's job, not train()'s")
+    if instances and isinstance(optim, torch.optim.Optimizer):
+        return optim
+    raise ValueError("optim must be 'SGD', 'Adam', 'AdamW'" + (" or a torch optimiser instance" if instances else ""))
+
+
+class _Log:
+    """The ``results`` dictionary of the reference's loop: "loss", "delta_loss" and one list per parameter -- with a
+    Lightcurve the keys and (constrained) values of ``get_parameters()``, starting with the values before the first step;
+    without one the raw parameters under their full names (and an empty list under the reference's short key)."""
+
+    def __init__(self, lightcurve, model):
+        self.lightcurve, self.model = lightcurve, model
+        self.results = {"loss": [], "delta_loss": []}
+        if lightcurve is not None:
+            for key, value in lightcurve.get_parameters().items():
+                self.results[key] = [value.cpu().detach().numpy()]
+        else:
+            for name, _ in model.named_parameters():
+                self.results[name.split(".")[1] if "raw" in name else name] = []
+                self.results.setdefault(name, [])
+
+    def loss(self, value):
+        if self.results["loss"]:
+            self.results["delta_loss"].append(value - self.results["loss"][-1])
+        self.results["loss"].append(value)
+
+    def parameters_now(self):
+        if self.lightcurve is not None:
+            for key, value in self.lightcurve.get_parameters().items():
+                self.results[key].append(value.cpu().detach().numpy())
+        else:
+            for name, p in self.model.named_parameters():
+                self.results[name].append(p.cpu().detach().numpy())
+
+    def converged(self, i, miniter, stop, stopavg):
+        """The reference's stop rule (``trainers.py:200-207``): after ``miniter`` iterations, the standard deviation of the
+        last ``stopavg`` losses below ``stop``."""
+        if not stop or i <= miniter:
+            return False
+        spread = np.std(self.results["loss"][-stopavg:])
+        if spread < stop:
+            print(f"Average change in loss over the last {stopavg} iterations was {spread}.\n"
+                  f" This is < {stop}, so we will end training here.")
+            return True
+        return False
+
+
 def train(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10,
           stop=None, lr=1e-4, lossfn="mll", optim="SGD", eps=1e-8, stopavg=9, progress=True, **kwargs):
-    given = [model is not None, likelihood is not None, train_x is not None, train_y is not None]
-    if lightcurve is not None:
-        if any(given):
-            print("A lightcurve object was passed to train(), but one or more of model, likelihood, train_x and "
-                  "train_y were also passed. The lightcurve object will be used, and the other parameters will be ignored.")
-        model, likelihood = lightcurve.model, lightcurve.likelihood
-        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
-    elif not all(given):
-        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
-                         "and train_y **must** be passed to train().")
-
+    """The reference's loop with its arguments, ``results`` and stop rule; the body is ``trainers.py:177-182`` verbatim in
+    meaning: zero_grad, ``model(x)``, ``-mll``, backward, step -- one fused HIP evaluation per iteration -- then the
+    per-iteration host read of the loss and the parameters (``:184-195``)."""
+    model, likelihood, train_x, train_y = _problem(lightcurve, model, likelihood, train_x, train_y)
     model.train()
     likelihood.train()
-
-    if isinstance(lossfn, str):
-        if lossfn == "mll":
-            lossfn = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
-        elif lossfn == "elbo":
-            raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented. "
-                                      "Using elbo will be implemented soon")
-        else:
-            raise ValueError("lossfn must be either 'mll', 'elbo', or a gpytorch, torch or pyro loss function.")
-    elif isinstance(lossfn, gpytorch.mlls.marginal_log_likelihood.MarginalLogLikelihood):
-        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented. "
-                                  "Passing arbitrary MLL objects will be implemented soon.")
-    else:
-        raise ValueError("lossfn must be either 'mll', 'elbo', or a gpytorch, torch or pyro loss function.")
-
-    bad_optim = "optim must be either 'SGD', 'Adam', 'AdamW', 'NUTS', or an instance of a torch or pyro optimiser."
-    if isinstance(optim, str):
-        if optim == "SGD":
-            optimizer = torch.optim.SGD(model.parameters(), lr=lr)
-        elif optim == "Adam":
-            optimizer = torch.optim.Adam(model.parameters(), lr=lr, eps=eps)
-        elif optim == "AdamW":
-            optimizer = torch.optim.AdamW(model.parameters(), lr=lr, eps=eps)
-        elif optim == "NUTS":
-            raise NotImplementedError("Optimisation with NUTS/MCMC is not yet implemented.")
-        else:
-            raise ValueError(bad_optim)
-    elif isinstance(optim, torch.optim.Optimizer):
-        optimizer = optim
-    else:
-        raise ValueError(bad_optim)
-
-    results = {"loss": [], "delta_loss": []}
-    if lightcurve is not None:
-        for key, value in lightcurve.get_parameters().items():
-            results[key] = [value.cpu().detach().numpy()]
-    else:
-        for name, _ in model.named_parameters():
-            key = name.split(".")[1] if "raw" in name else name
-            results[key] = []
-            results.setdefault(name, [])
-
+    objective = _mll_objective(lossfn, likelihood, model)
+    optimizer = _optimiser(optim, model.parameters(), lr, eps)
+    log = _Log(lightcurve, model)
     for i in _iterate(maxiter, progress):
         optimizer.zero_grad()
-        output = model(train_x)
-        loss = -lossfn(output, train_y)
+        loss = -objective(model(train_x), train_y)
         loss.backward()
         optimizer.step()
-        value = loss.cpu().detach().numpy()
-        if i > 0:
-            results["delta_loss"].append(value - results["loss"][-1])
-        results["loss"].append(value)
-        if lightcurve is not None:
-            for key, val in lightcurve.get_parameters().items():
-                results[key].append(val.cpu().detach().numpy())
-        else:
-            for name, param in model.named_parameters():
-                results[name].append(param.cpu().detach().numpy())
-        if stop and i > miniter:
-            stopval = np.std(results["loss"][-stopavg:])
-            if stopval < stop:
-                print(f"Average change in loss over the last {stopavg} iterations was {stopval}.\n"
-                      f" This is < {stop}, so we will end training here.")
-                break
-    return results
+        log.loss(loss.cpu().detach().numpy())
+        log.parameters_now()
+        if log.converged(i, miniter, stop, stopavg):
+            break
+    return log.results
 
 
 def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=None, maxiter=100, miniter=10,
@@ -120,32 +144,19 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
     factorisation surfaces as a non-finite loss (``NanError``, with the last good parameters
     restored) instead of the jitter retry, and ``optim`` must be one of the string choices.
     """
+    from . import _hip
     from .gpytorch import settings
     from .gpytorch.utils.errors import NanError
-    if lightcurve is not None:
-        model, likelihood = lightcurve.model, lightcurve.likelihood
-        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
-    elif any(v is None for v in (model, likelihood, train_x, train_y)):
-        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
-                         "and train_y **must** be passed to train().")
-    if lossfn != "mll":
-        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
+    model, likelihood, train_x, train_y = _problem(lightcurve, model, likelihood, train_x, train_y)
     if not train_x.is_cuda:
         raise RuntimeError("train_device needs the model and data on the GPU")
     # (constraint bounds registered after the model moved to the GPU are host tensors: inside the captured iteration their
     #  transfer would be an illegal host-to-device copy)
     model.to(train_x.device); likelihood.to(train_x.device)
     model.train(); likelihood.train()
-    mll = gpytorch.mlls.ExactMarginalLogLikelihood(likelihood, model)
+    mll = _mll_objective(lossfn, likelihood, model)
     params = [p for p in model.parameters() if p.requires_grad]
-    if optim == "SGD":
-        optimizer = torch.optim.SGD(params, lr=lr)
-    elif optim == "Adam":
-        optimizer = torch.optim.Adam(params, lr=lr, eps=eps, capturable=True)
-    elif optim == "AdamW":
-        optimizer = torch.optim.AdamW(params, lr=lr, eps=eps, capturable=True)
-    else:
-        raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the device-resident loop.")
+    optimizer = _optimiser(optim, params, lr, eps, instances=False, **({} if optim == "SGD" else {"capturable": True}))
 
     names = [n for n, _ in model.named_parameters()]
     named = dict(model.named_parameters())
@@ -181,14 +192,11 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
             for n, p in named.items():
                 p.copy_(state[n])
 
-        results = {"loss": [], "delta_loss": []}
-        if lightcurve is not None:
-            for key, value in lightcurve.get_parameters().items():
-                results[key] = [value.cpu().detach().numpy()]
-        else:
-            for n in names:
-                results[n.split(".")[1] if "raw" in n else n] = []
-                results.setdefault(n, [])
+        # the captured iteration has the addresses of the workspace it ran on baked in: hold every workspace the warm-up
+        # touched for as long as the graph is replayed (the cache may otherwise drop -- and thereby free -- it)
+        held = _hip.cached_workspaces(dev)
+        log = _Log(lightcurve, model)
+        results = log.results
         loss_hist = torch.zeros(maxiter, dtype=train_y.dtype, device=dev)
         par_hist = {n: torch.zeros((maxiter,) + tuple(p.shape), dtype=p.dtype, device=dev) for n, p in named.items()}
         done, stopped = 0, False
@@ -209,13 +217,8 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                 raise NanError("non-finite loss in the device-resident loop (factorisation failed or NaN parameters)")
             for off in range(blk):
                 i = done + off
-                value = host_loss[off]
-                if i > 0:
-                    results["delta_loss"].append(value - results["loss"][-1])
-                results["loss"].append(value)
-                if stop and i > miniter and np.std(results["loss"][-stopavg:]) < stop:
-                    print(f"Average change in loss over the last {stopavg} iterations was "
-                          f"{np.std(results['loss'][-stopavg:])}.\\n This is < {stop}, so we will end training here.")
+                log.loss(host_loss[off])
+                if log.converged(i, miniter, stop, stopavg):
                     stopped = True
                     blk = off + 1
                     break
@@ -234,6 +237,7 @@ def train_device(lightcurve=None, model=None, likelihood=None, train_x=None, tra
             raw_hist = {n: par_hist[n][:n_done].cpu().numpy() for n in names}
             for key, rows in _lightcurve_traces(lightcurve, raw_hist).items():
                 results[key].extend(rows)
+        del held
     return results
 
 
@@ -395,26 +399,14 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
     good parameters in the model."""
     from . import _hip
     from .gpytorch.utils.errors import NanError
-    if lightcurve is not None:
-        model, likelihood = lightcurve.model, lightcurve.likelihood
-        train_x, train_y = lightcurve._xdata_transformed, lightcurve._ydata_transformed
-    elif any(v is None for v in (model, likelihood, train_x, train_y)):
-        raise ValueError("If a lightcurve object is not passed to train(), **all** of model, likelihood, train_x "
-                         "and train_y **must** be passed to train().")
-    if lossfn != "mll":
-        raise NotImplementedError("Currently only maximisation of the marginal log-likelihood is implemented.")
+    model, likelihood, train_x, train_y = _problem(lightcurve, model, likelihood, train_x, train_y)
+    _mll_objective(lossfn, likelihood, model)                  # (argument check only: the native loop is the exact MLL)
     if optim not in _hip.NativeFit.OPT:
-        raise ValueError("optim must be either 'SGD', 'Adam' or 'AdamW' for the native loop.")
+        _optimiser(optim, [], lr, eps, instances=False)         # raises the loop's own error for anything else
     fit, pieces, raw0 = _native_fit_handle(model, likelihood, train_x, train_y, maxiter, lr, optim, eps)
-    results = {"loss": [], "delta_loss": []}
+    log = _Log(lightcurve, model)
+    results = log.results
     names = [n_ for n_, _ in model.named_parameters()]
-    if lightcurve is not None:
-        for key, value in lightcurve.get_parameters().items():
-            results[key] = [value.cpu().detach().numpy()]
-    else:
-        for n_ in names:
-            results[n_.split(".")[1] if "raw" in n_ else n_] = []
-            results.setdefault(n_, [])
 
     def write_back(row):
         off = 0
@@ -437,13 +429,8 @@ def train_native(lightcurve=None, model=None, likelihood=None, train_x=None, tra
                 write_back(hist[good - 1] if good > 0 else np.asarray(raw0))           # the last parameters a finite loss produced
                 raise NanError("non-finite loss in the native loop (factorisation failed or NaN parameters)")
             for off, value in enumerate(new):
-                i = done + off
-                if i > 0:
-                    results["delta_loss"].append(value - results["loss"][-1])
-                results["loss"].append(value)
-                if stop and i > miniter and np.std(results["loss"][-stopavg:]) < stop:
-                    print(f"Average change in loss over the last {stopavg} iterations was "
-                          f"{np.std(results['loss'][-stopavg:])}.\n This is < {stop}, so we will end training here.")
+                log.loss(value)
+                if log.converged(done + off, miniter, stop, stopavg):
                     stopped = True
                     break
             done = k_done

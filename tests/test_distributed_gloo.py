@@ -124,3 +124,48 @@ def test_partitioning_rules():
     loads = [sum(c for c, o in zip([n ** 3 for n in (4096, 512, 512, 2048, 2048, 256)], owner) if o == r) for r in range(2)]
     assert max(loads) == 4096 ** 3            # the big one alone, the rest together
     assert gather_logliks(torch.arange(3.0), 3).tolist() == [0.0, 1.0, 2.0]     # single process: identity
+
+
+def test_self_launcher_starts_one_rank_per_device_and_relays_rank_0():
+    """``bench.py --gpus N`` without torch.distributed.run: ``pgmuvi_amd.launch.spawn_ranks`` starts N fresh children of the
+    command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and returns the children's
+    worst status.  Here: two gloo ranks on the CPU with the oracle stand-in (``tests/_launch_worker.py``), against one process
+    evaluating the whole batch; a rank that dies before the rendezvous takes the job down with its status; too few devices
+    are refused before anything is started."""
+    import io
+    import json
+    import _oracle_backend as ob
+    from pgmuvi_amd import launch
+    worker = os.path.join(ROOT, "tests", "_launch_worker.py")
+    total, n = 5, 40
+    buf = io.StringIO()
+    rc = launch.spawn_ranks([sys.executable, worker, "--gpus", "2", "--total-batch", str(total), "--npoints", str(n)], 2, out=buf)
+    assert rc == 0
+    got = json.loads([ln for ln in buf.getvalue().splitlines() if ln.startswith("{")][-1])
+    assert got["world"] == 2 and got["gpus_arg"] == 2 and got["child_mark"] == "1" and got["master"][0] == "127.0.0.1"
+    assert got["ranks"] == [[0, 0, 3], [1, 1, 2]]                 # rank == local rank, block partition 3 + 2
+    whole = make_shard(total, 0, 1, n, "cfg3")
+    _, ref = sharded_batch_step(whole, total, None, _compute=ob.mll_value_grad)
+    assert got["loglik"] == ref.tolist()
+    # a rank that fails: its status comes back, the rank left waiting in the rendezvous is stopped
+    buf = io.StringIO()
+    rc = launch.spawn_ranks([sys.executable, worker, "--gpus", "2", "--fail-rank", "1"], 2, grace_s=2.0, out=buf)
+    assert rc == 3 and "{" not in buf.getvalue()
+    # fewer visible devices than ranks: refused, nothing started
+    err = io.StringIO()
+    assert launch.spawn_ranks([sys.executable, "-c", "raise SystemExit(0)"], 2, visible_devices=1, err=err) == 2
+    assert "needs 2 visible GPUs" in err.getvalue()
+    env = launch.rank_environment(3, 8, 12345, base={})
+    assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "12345")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and launch.under_a_launcher(env) and not launch.under_a_launcher({})
+
+
+def test_bench_refuses_more_ranks_than_devices_before_touching_a_gpu():
+    """``python bench.py --gpus 2`` on a box without two GPUs: one line on stderr, status 2, no rank started."""
+    import subprocess
+    import torch as _t
+    if _t.cuda.device_count() >= 2:
+        pytest.skip("two devices visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--no-cpu"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""

@@ -1468,20 +1468,27 @@ def test_c_abi_from_a_c_caller(dev):
 
 
 def test_bench_collective_path_on_rccl(dev):
-    """``bench.py`` launched the way the driver launches the multi-GPU runs (``python -m torch.distributed.run``), with one
-    rank and ``PGM_BENCH_DIST=1`` so that the process group is RCCL ("nccl") even on this one-GPU box: barrier, the
+    """``bench.py`` as a one-rank RCCL job on this one-GPU box, started both ways the driver may start the multi-GPU runs:
+    plainly (``python bench.py --gpus N``: the self-launcher of ``pgmuvi_amd.launch`` starts the ranks -- ``--spawn`` takes that
+    path with N = 1) and under ``python -m torch.distributed.run``.  The process group is RCCL ("nccl"): barrier, the
     all_gather of the log-likelihoods of both modes and the max-over-ranks timing all go through the collective library."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PGM_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-            "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu"]
-    for extra, scaling in ((["--npoints", "1024", "--no-extra"], "weak"), (["--npoints", "512", "--total-batch", "24", "--chunk", "8"], "strong")):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    common = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    plain = [sys.executable, os.path.join(root, "bench.py"), "--spawn"] + common
+    torchrun = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29617", os.path.join(root, "bench.py")] + common
+    for base, extra, scaling in ((plain, ["--npoints", "1024", "--no-extra"], "weak"),
+                                 (torchrun, ["--npoints", "512", "--total-batch", "24", "--chunk", "8"], "strong")):
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=280, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         out = json.loads(line)
         assert out["scaling"] == scaling and out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+        assert out["roofline_build"]["frac"] > 0 and out["roofline_build"]["exp_issue_floor_us"] > 0
 
 
 def test_performance_guards(dev):
