@@ -10,9 +10,20 @@
 // B[k = l>>4][j = l&15]; D: col = l&15, row = (l>>4) + 4*reg).
 //
 // 256 threads = 4 wavefronts (64 lanes), one per SIMD; each wave owns a WM x WN
-// sub-tile as TM x TN MFMA tiles with the accumulators in registers.  k advances in
-// chunks of KB=16 rows, double-buffered in LDS with the next chunk's global loads in
-// flight behind the current chunk's MFMAs (one barrier per chunk).
+// sub-tile as TM x TN MFMA tiles with the accumulators in registers.
+//
+// Two forms of the loop:
+//  * staged (DIRECT = false): k advances in chunks of KB=16 rows, double-buffered in LDS with the next chunk's global
+//    loads in flight behind the current chunk's MFMAs (one barrier per chunk).
+//  * direct (DIRECT = true, round 3): NO LDS.  The rows of a wave's sub-tile are dealt to its MFMA tiles round-robin --
+//    MFMA tile ti holds rows m0 + TM i + ti, i = 0..15 -- so lane (k = l>>4, i = l&15) needs A[k][m0 + TM i .. + TM-1]:
+//    TM contiguous doubles, and one k-step (4 rows) of ALL the wave's A fragments is one or two 16-byte loads per lane,
+//    4 x (8 TM 16)-byte contiguous runs per wavefront, straight from memory into the MFMA operand registers; the same for
+//    B.  No staging registers -> LDS stores -> barrier -> LDS reads: 4 loads and 16 MFMAs per k-step, wavefronts never wait
+//    for one another, PF k-steps of fragments in flight.  Measured (tools/lab/directlab, 128x128 tiles, 2 workgroups per
+//    CU): 0.95 of the fp64 MFMA peak at k-depth 2048 on L2-hot operands against 0.85 staged, 0.875 / 0.80 at k-depth 512,
+//    0.82 / 0.75 at 256; on operands streamed from HBM 0.88 / 0.87, 0.84 / 0.82, 0.85 / 0.80.  Each element still
+//    receives the k-steps in ascending order from the same start value: same bits as the staged loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,8 +35,9 @@ constexpr int NB = 128;   // block size of the blocked algorithms (rows per k-bl
 constexpr int KB = 16;    // k rows staged per LDS chunk
 constexpr int NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1, int NT_ = 256, int KB_ = KB>
+template <int BM_, int BN_, int WM_, int WN_, int PF_ = 1, int NT_ = 256, int KB_ = KB, bool DIRECT_ = false>
 struct TileCfg {
+  static constexpr bool DIRECT = DIRECT_;   // fragments straight from memory (PF = k-steps in flight), no LDS staging
   static constexpr int KC = KB_;          // k rows staged per LDS chunk (one barrier per chunk)
   static constexpr int NT = NT_;          // threads per workgroup: 4 wavefronts, or 16 for the filler tiles of k_diag
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
@@ -34,7 +46,7 @@ struct TileCfg {
   // prefetched chunk leaves the loop latency-bound; PF > 1 hides it
   static constexpr int PF = PF_;
   static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8, "prefetch depth must divide the chunks per k-block");
-  static_assert((NB / KB_) % PF_ == 0 && KB_ % 4 == 0, "chunking");
+  static_assert(DIRECT_ ? (NB / 4) % PF_ == 0 : ((NB / KB_) % PF_ == 0 && KB_ % 4 == 0), "chunking");
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == NT / 64, "one WM x WN sub-tile per wavefront");
@@ -67,9 +79,98 @@ __device__ __forceinline__ WavePos wave_pos() {
 }
 // element (ti, tj, r) of a wave's accumulator sits at tile-local (row, col):
 template <class C>
-__device__ __forceinline__ int acc_row(const WavePos& p, int ti, int r) { return p.m0 + ti * 16 + (p.lane >> 4) + 4 * r; }
+__device__ __forceinline__ int acc_row(const WavePos& p, int ti, int r) {
+  if constexpr (C::DIRECT) return p.m0 + C::TM * ((p.lane >> 4) + 4 * r) + ti;        // (rows dealt round-robin to the MFMA tiles)
+  else return p.m0 + ti * 16 + (p.lane >> 4) + 4 * r;
+}
 template <class C>
-__device__ __forceinline__ int acc_col(const WavePos& p, int tj) { return p.n0 + tj * 16 + (p.lane & 15); }
+__device__ __forceinline__ int acc_col(const WavePos& p, int tj) {
+  if constexpr (C::DIRECT) return p.n0 + C::TN * (p.lane & 15) + tj;
+  else return p.n0 + tj * 16 + (p.lane & 15);
+}
+
+// n contiguous doubles (n = 1, 2, 4) at an address that is a multiple of 8 n bytes: one or two 16-byte accesses
+template <int N>
+__device__ __forceinline__ void load_run(const double* __restrict__ p, double (&x)[N]) {
+  static_assert(N == 1 || N == 2 || N == 4, "run length");
+  if constexpr (N == 1) x[0] = p[0];
+  else {
+#pragma unroll
+    for (int h = 0; h < N / 2; ++h) { const v2d v = *reinterpret_cast<const v2d*>(p + 2 * h); x[2 * h] = v[0]; x[2 * h + 1] = v[1]; }
+  }
+}
+template <int N>
+__device__ __forceinline__ void store_run(double* __restrict__ p, const double (&x)[N]) {
+  if constexpr (N == 1) p[0] = x[0];
+  else {
+#pragma unroll
+    for (int h = 0; h < N / 2; ++h) *reinterpret_cast<v2d*>(p + 2 * h) = v2d{x[2 * h], x[2 * h + 1]};
+  }
+}
+
+// the direct loop (see the head of this file).  Addressing is kept off the vector unit: per k-block one buffer descriptor
+// per operand (scalar registers) and one 32-bit lane offset, per k-step a scalar row offset -- a load is
+// `buffer_load_dwordx4 v, voff, s[desc], soff offen`, no 64-bit address arithmetic per lane (with plain global loads the
+// address math of every k-step cost more than the LDS staging it replaced).
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void load_frag(const __amdgpu_buffer_rsrc_t rs, int voff, int soff, double (&x)[N]) {
+  static_assert(N == 1 || N == 2 || N == 4, "fragment run");
+  if constexpr (N == 1) x[0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+  else {
+#pragma unroll
+    for (int h = 0; h < N / 2; ++h) {
+      const v2d v = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * h, soff, 0));
+      x[2 * h] = v[0]; x[2 * h + 1] = v[1];
+    }
+  }
+}
+struct OperandBlock { __amdgpu_buffer_rsrc_t ra, rb; int voa, vob, sa, sb; };   // descriptors, lane offsets, bytes per k-step
+template <class C, class PtrFn>
+__device__ __forceinline__ void gemm_direct(int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late) {
+  const WavePos wp = wave_pos<C>();
+  constexpr int PD = C::PF, TM = C::TM, TN = C::TN, KS = NB / 4;      // k-steps per k-block
+  static_assert(KS % PD == 0 && PD < KS, "prefetch distance");
+  const int g = wp.lane >> 4, i = wp.lane & 15;
+  const int ca = (wp.m0 + TM * i) * 8, cb = (wp.n0 + TN * i) * 8;
+  auto block = [&](int kb) {
+    const double* pa; const double* pb; int64_t lda, ldb;
+    ptrs(kb, pa, lda, pb, ldb);                                        // (uniform: scalar registers)
+    OperandBlock o;
+    o.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pa), 0, 0x7fffffff, 0x00027000);
+    o.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pb), 0, 0x7fffffff, 0x00027000);
+    o.voa = g * (int)lda * 8 + ca; o.vob = g * (int)ldb * 8 + cb;
+    o.sa = 4 * (int)lda * 8; o.sb = 4 * (int)ldb * 8;
+    return o;
+  };
+  double a[PD][TM], b[PD][TN];
+  auto load = [&](int u, int ks) {                                     // k-step ks -> stage u
+    const OperandBlock o = block(ks / KS);                             // (scalar work: it rides in the shadow of the MFMAs)
+    const int kr = ks % KS;
+    load_frag<TM>(o.ra, o.voa, kr * o.sa, a[u]); load_frag<TN>(o.rb, o.vob, kr * o.sb, b[u]);
+  };
+  const int nks = nkb * KS;
+#pragma unroll
+  for (int u = 0; u < PD; ++u) load(u, u);
+  if (negate_late) {                                                   // acc holds +C from acc_load_raw: its loads and the first
+#pragma unroll                                                         // fragments' are one memory round trip instead of two
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = -acc[ti][tj];
+  }
+  for (int ks0 = 0; ks0 < nks; ks0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], b[u][tj], acc[ti][tj], 0, 0, 0);
+      if (ks0 + u + PD < nks) load(u, ks0 + u + PD);                   // the stage is free again
+    }
+  }
+}
 
 // ptrs(kb, pa, lda, pb, ldb): operand tile pointers of k-block kb: A tile is
 // NB x BM at pa (row pitch lda), B tile NB x BN at pb.
@@ -78,6 +179,7 @@ __device__ __forceinline__ int acc_col(const WavePos& p, int tj) { return p.n0 +
 template <class C, class PtrFn>
 __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn&& ptrs,
                                         v4d (&acc)[C::TM][C::TN], int bsplit = 0, bool negate_late = false) {
+  if constexpr (C::DIRECT) { gemm_direct<C>(nkb, ptrs, acc, negate_late); return; }   // (bsplit: staged form only)
   const int t = threadIdx.x;
   const WavePos wp = wave_pos<C>();
   constexpr int KC = C::KC;
@@ -153,30 +255,36 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
   }
 }
 
-// acc = -C (so that the accumulated result is -(C - A^T B)); C tile at c, pitch ldc
+// acc = scale * C; C tile at c, pitch ldc
 template <class C>
-__device__ __forceinline__ void acc_load_neg(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) {
+__device__ __forceinline__ void acc_load_scaled(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN], double scale) {
   const WavePos wp = wave_pos<C>();
+  if constexpr (C::DIRECT) {       // a lane's TN columns of one row are contiguous: 16-byte accesses, 16 TN 8-byte runs per row
 #pragma unroll
-  for (int ti = 0; ti < C::TM; ++ti)
+    for (int ti = 0; ti < C::TM; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < C::TN; ++tj)
+      for (int r = 0; r < 4; ++r) {
+        double x[C::TN];
+        load_run<C::TN>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[ti][tj][r] = -c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)];
+        for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj][r] = scale * x[tj];
+      }
+  } else {
+#pragma unroll
+    for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[ti][tj][r] = scale * c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)];
+  }
 }
+// acc = -C (so that the accumulated result is -(C - A^T B))
+template <class C>
+__device__ __forceinline__ void acc_load_neg(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C>(c, ldc, acc, -1.0); }
 // acc = +C, to be negated by gemm_tn(..., negate_late = true) once the first operand chunks are on their way
 template <class C>
-__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) {
-  const WavePos wp = wave_pos<C>();
-#pragma unroll
-  for (int ti = 0; ti < C::TM; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < C::TN; ++tj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[ti][tj][r] = c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)];
-}
+__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C>(c, ldc, acc, 1.0); }
 template <class C>
 __device__ __forceinline__ void acc_negate(v4d (&acc)[C::TM][C::TN]) {
 #pragma unroll
@@ -195,11 +303,23 @@ __device__ __forceinline__ void acc_zero(v4d (&acc)[C::TM][C::TN]) {
 template <class C>
 __device__ __forceinline__ void acc_store(double* __restrict__ c, int64_t ldc, const v4d (&acc)[C::TM][C::TN], double sign) {
   const WavePos wp = wave_pos<C>();
+  if constexpr (C::DIRECT) {
 #pragma unroll
-  for (int ti = 0; ti < C::TM; ++ti)
+    for (int ti = 0; ti < C::TM; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < C::TN; ++tj)
+      for (int r = 0; r < 4; ++r) {
+        double x[C::TN];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)] = sign * acc[ti][tj][r];
+        for (int tj = 0; tj < C::TN; ++tj) x[tj] = sign * acc[ti][tj][r];
+        store_run<C::TN>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
+      }
+  } else {
+#pragma unroll
+    for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          c[(int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, tj)] = sign * acc[ti][tj][r];
+  }
 }

@@ -86,6 +86,9 @@ struct pgm_ws {
   double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
+  int strips_min;        // batches: k_trsm_strips from this many block rows x light curves on
+  int strips;            // batches: row solve by k_trsm_strips
+  int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
   int build_beside;      // one light curve, 1-D spectral mixture: build the matrix below block row 0 beside diagonal block 0 (PGM_BUILD_BESIDE=0: off)
   int lazy, lazy_end;    // fused sweep: lazy plan (run_sweep), and the tile count from which it turns eager

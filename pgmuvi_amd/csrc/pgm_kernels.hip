@@ -472,7 +472,18 @@ __device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, in
 #ifndef PGM_FILL_KB
 #define PGM_FILL_KB 16
 #endif
+// (direct form of the multiply loop, pgm_gemm.h: fragments straight from memory, 8 k-steps in flight per wavefront)
+#ifndef PGM_DIRECT_FILL
+#define PGM_DIRECT_FILL 1
+#endif
+#ifndef PGM_FILL_PD
+#define PGM_FILL_PD 4
+#endif
+#if PGM_DIRECT_FILL
+using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PD, DIAG_THREADS, KB, true>;
+#else
 using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PF, DIAG_THREADS, PGM_FILL_KB>;
+#endif
 static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit the diagonal block image");
 
 // (A persistent variant -- one filler workgroup per CU looping over tiles with the next tile's C
@@ -854,7 +865,7 @@ __device__ __forceinline__ void trsm_slab(const PgmDev& P, double* lds, double* 
 #pragma unroll
     for (int ti = 0; ti < C::TM; ++ti)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s += acc[ti][tj][r] * zs[acc_row<C>(wp, ti, r)];
+      for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[ti][tj][r], zs[acc_row<C>(wp, ti, r)], s);
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     if (wp.lane < 16) red[wp.wave][tj * 16 + wp.lane] = s;
@@ -941,6 +952,121 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
 }
 
 // ---------------------------------------------------------------------------
+// The row solve of batches (panel / left-looking sweeps, where the launch is throughput work, not a link of a latency chain).
+// The slab kernel above runs one 128-deep product per workgroup behind a fresh copy of U_kk^-1: 160 KB fetched for 2 us of
+// MFMA, the launch bound by prologues (64 x N=2048: 97 us per block row at a quarter of the matrix pipe).  Here a workgroup
+// keeps U_kk^-1 in LDS for its whole life (147 KB: one workgroup per CU) and its 8 wavefronts stream 16-column strips of
+// the block row through it, each on its own: the strip's 128 x 16 values go straight from memory into MFMA B fragments
+// (32 eight-byte loads per lane, all in flight at once), the A fragments come from the LDS image -- no staging stores, no
+// barrier after the prologue.  U_kk^-1 is upper triangular ([p][m], zero for p > m), so k-step kk only reaches the 16-row
+// output tiles ti >= kk / 4: 144 MFMAs per strip instead of 256, every wavefront the same number.  The MFMAs that are left
+// out would add exact zeros, the others run in the slab kernel's order (k ascending from a zero accumulator), and the
+// forward-substitution sums are formed in the slab kernel's order too (pairs of 16-row tiles, butterfly over the row
+// groups, the four 32-row groups top to bottom): same bits as k_trsm.
+// ---------------------------------------------------------------------------
+constexpr int STRIP_THREADS = 512, STRIP_W = 16;
+__global__ __launch_bounds__(STRIP_THREADS, 2) void k_trsm_strips(PgmDev P, int k, int nblocks) {
+  __shared__ __attribute__((aligned(16))) double Ui[NB * PM];
+  __shared__ double zs[NB];
+  const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+  {  // U_kk^-1 -> LDS (16 x 16-B loads per thread, all in flight)
+    constexpr int NV = NB * NB / 2 / STRIP_THREADS;
+    v2d tmp[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = t + u * STRIP_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+      tmp[u] = *reinterpret_cast<const v2d*>(Uinv + row * NB + c2);
+    }
+    if (t < NB) zs[t] = P.z[b * P.sVec + k * NB + t];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = t + u * STRIP_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
+      *reinterpret_cast<v2d*>(Ui + row * PM + c2) = tmp[u];
+    }
+  }
+  __syncthreads();
+  double* A = P.A + b * P.sA;
+  const int64_t ld = P.ld;
+  const int g = lane >> 4, n = lane & 15;
+  constexpr int SPB = NB / STRIP_W;                           // strips per block
+  const int nstrips = nblocks * SPB;
+  const int stride = (int)gridDim.x * (STRIP_THREADS / 64);
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  // (buffer addressing: a uniform descriptor per strip, the row as a scalar offset and ONE 32-bit lane offset -- the 32 loads
+  //  and 32 stores of a strip share a single address register instead of 64 address pairs)
+  const int voff = (g * (int)ld + n) * 8, rowb = (int)ld * 8;
+  auto strip_block = [&](int sidx) { int jb = sidx / SPB; if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; } return jb; };
+  auto strip_desc = [&](int sidx) {
+    double* Cs = A + (int64_t)k * NB * ld + strip_block(sidx) * NB + (sidx % SPB) * STRIP_W;     // uniform
+    return __builtin_amdgcn_make_buffer_rsrc(Cs, 0, 0x7fffffff, 0x00027000);
+  };
+  int sidx = (int)blockIdx.x * (STRIP_THREADS / 64) + wave;
+  if (sidx >= nstrips) return;
+  __amdgpu_buffer_rsrc_t rs = strip_desc(sidx);
+  double bf[NB / 4];
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) bf[kk] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 4 * kk * rowb, 0));
+  const double* arow0 = Ui + g * PM + n;
+  for (;;) {
+    // the NEXT strip's values are requested while this one is multiplied, half a strip at a time into the fragment
+    // registers the MFMAs have just released: the wavefront never sits out a memory round trip between two strips
+    const int nxt = sidx + stride;
+    const bool more = nxt < nstrips;                             // (uniform)
+    const __amdgpu_buffer_rsrc_t rn = strip_desc(more ? nxt : sidx);
+    v4d acc[NB / 16];
+#pragma unroll
+    for (int ti = 0; ti < NB / 16; ++ti) acc[ti] = v4d{0.0, 0.0, 0.0, 0.0};
+    // A fragments one k-step ahead of the MFMAs that use them (the fence keeps the compiler from hoisting all 144 LDS reads
+    // to the top, which spills)
+    double af[2][NB / 16];
+#pragma unroll
+    for (int ti = 0; ti < NB / 16; ++ti) af[0][ti] = arow0[16 * ti];
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      if (kk + 1 < NB / 4) {
+        const double* arow = arow0 + 4 * (kk + 1) * PM;
+#pragma unroll
+        for (int ti = (kk + 1) / 4; ti < NB / 16; ++ti) af[(kk + 1) & 1][ti] = arow[16 * ti];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int ti = kk / 4; ti < NB / 16; ++ti)
+        acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk & 1][ti], bf[kk], acc[ti], 0, 0, 0);
+      if ((kk == NB / 8 - 1 || kk == NB / 4 - 1) && more) {      // the half just consumed: refill it for the next strip
+#pragma unroll
+        for (int q = kk + 1 - NB / 8; q <= kk; ++q) bf[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rn, voff, 4 * q * rowb, 0));
+      }
+    }
+#pragma unroll
+    for (int ti = 0; ti < NB / 16; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (double)acc[ti][r]), rs, voff, (16 * ti + 4 * r) * rowb, 0);
+    // forward substitution / alpha update of the strip's 16 columns (the summation order of trsm_slab)
+    double tot = 0.0;
+#pragma unroll
+    for (int mw = 0; mw < 4; ++mw) {
+      double sp = 0.0;
+#pragma unroll
+      for (int ti = 2 * mw; ti < 2 * mw + 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp = __builtin_fma(acc[ti][r], zs[16 * ti + g + 4 * r], sp);
+      sp += __shfl_xor(sp, 16, 64);
+      sp += __shfl_xor(sp, 32, 64);
+      tot += sp;
+    }
+    if (lane < STRIP_W) {
+      const int jb = strip_block(sidx);
+      const int64_t gi = b * P.sVec + jb * NB + (sidx % SPB) * STRIP_W + lane;
+      if (jb > k) P.r[gi] -= tot; else P.alpha[gi] += tot;
+    }
+    if (!more) break;
+    sidx = nxt; rs = rn;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Trailing update with a panel of `dp` finished block rows k0..k0+dp-1 (the dominant
 // kernel), applied to block rows r_lo..r_hi-1:
 //   A_rj -= sum_p U_pr^T U_pj        r <= j            (Cholesky trailing update)
@@ -999,7 +1125,16 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 #ifndef PGM_BIG_PF
 #define PGM_BIG_PF 2            // two chunks in flight: 64 x N=2048 13.83 -> 13.64 ms, 8 x N=4096 12.27 -> 12.19 ms
 #endif
-using CfgBig = TileCfg<128, 128, 64, 64, PGM_BIG_PF>;
+// the staged form keeps the name CfgBigLds: its LDS budget is what the gradient epilogues stage their factors in
+using CfgBigLds = TileCfg<128, 128, 64, 64, PGM_BIG_PF>;
+#ifndef PGM_DIRECT_BIG
+#define PGM_DIRECT_BIG 1
+#endif
+#if PGM_DIRECT_BIG
+struct CfgBig : TileCfg<128, 128, 64, 64, 4, 256, KB, true> { static constexpr int LDS_DOUBLES = CfgBigLds::LDS_DOUBLES; };
+#else
+using CfgBig = CfgBigLds;
+#endif
 #ifndef PGM_UPD_WAVES8
 #define PGM_UPD_WAVES8 0
 #endif
@@ -1011,7 +1146,14 @@ using CfgUpd = TileCfg<128, 128, 64, 32, PGM_UPD_PF, 512>;      // (experiment) 
 #else
 using CfgUpd = CfgBig;
 #endif
+#ifndef PGM_DIRECT_SMALL
+#define PGM_DIRECT_SMALL 1
+#endif
+#if PGM_DIRECT_SMALL
+using CfgSmall = TileCfg<64, 64, 32, 32, 8, 256, KB, true>;
+#else
 using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
+#endif
 using CfgSub = CfgSmall;                                     // quarter tiles of the inverse/gradient pass of short light curves
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).

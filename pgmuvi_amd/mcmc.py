@@ -487,6 +487,37 @@ def split_rhat(x: np.ndarray) -> np.ndarray:
     return np.sqrt(((h - 1) / h * w + b / h) / w)
 
 
+def effective_sample_size(x: np.ndarray) -> np.ndarray:
+    """Effective number of independent draws in (chains, samples, ...) -- Geyer's initial positive sequence on the
+    chain-averaged autocorrelations, as pyro's / Stan's diagnostics estimate it (BDA3 11.5)."""
+    x = np.asarray(x, dtype=float)
+    c, s = x.shape[:2]
+    flat = x.reshape(c, s, -1)
+    out = np.empty(flat.shape[2])
+    for k in range(flat.shape[2]):
+        v = flat[:, :, k] - flat[:, :, k].mean(axis=1, keepdims=True)
+        n = 1 << int(np.ceil(np.log2(2 * s)))
+        f = np.fft.rfft(v, n=n, axis=1)
+        acov = np.fft.irfft(f * np.conj(f), n=n, axis=1)[:, :s] / s          # biased autocovariances per chain
+        w = acov[:, 0].mean() * s / (s - 1.0)
+        var_plus = w * (s - 1.0) / s
+        if c > 1:
+            var_plus += flat[:, :, k].mean(axis=1).var(ddof=1)
+        if not (var_plus > 0):
+            out[k] = float(c * s)
+            continue
+        rho = 1.0 - (w - acov.mean(axis=0)) / var_plus
+        tau, t = -1.0, 0
+        while t + 1 < s:
+            pair = rho[t] + rho[t + 1]
+            if pair < 0:
+                break
+            tau += 2.0 * pair
+            t += 2
+        out[k] = c * s / max(tau, 1.0 / np.log10(max(c * s, 10)))
+    return out.reshape(x.shape[2:])
+
+
 def run_mcmc(x, y, noise=None, num_mixtures=4, sampler="NUTS", num_samples=500, warmup_steps=100, num_chains=1, seed=0,
              initial_values: Optional[Dict[str, np.ndarray]] = None, priors=None, dim_order=0, group=None, compute=None,
              group_by_chain=False, **sampler_kwargs):

@@ -314,6 +314,31 @@ def test_posterior_prediction_vs_oracle(dev, golden_dir):
     assert torch.allclose((hi - lo).cpu(), 4 * pv.clamp_min(0).sqrt(), atol=1e-7)
 
 
+def test_posterior_prediction_at_the_reference_size(dev):
+    """Eval-mode prediction the way ``Lightcurve.plot()`` / ``to_table()`` ask for it (/root/reference/pgmuvi/lightcurve.py:9607-9623:
+    ``torch.linspace(x.min(), x.max(), 10000)`` under ``fast_pred_var``) at the headline size: N = 4096 training points (config 2's
+    light curve), 10 000 test points, against the oracle's dense posterior."""
+    t, y, e = syn.cfg2(n_obs=4096)
+    x, y, noise = t.double(), y.double(), e.double() ** 2
+    h = syn.cfg_hypers(2, y)
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(noise.to(dev))
+    model = _make_model(dev, x.to(dev), y.to(dev), lik, 4)
+    model.initialize(**{"covar_module.mixture_weights": h["w"].to(dev), "covar_module.mixture_means": h["mu"].to(dev),
+                        "covar_module.mixture_scales": h["v"].to(dev), "mean_module.constant": h["mean"].to(dev)})
+    model.eval(); lik.eval()
+    xs = torch.linspace(float(x.min()), float(x.max()), 10000, dtype=D)
+    with torch.no_grad(), g.settings.fast_pred_var(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pred = lik(model(xs.to(dev)))
+        mean, var = pred.mean.cpu(), pred.variance.cpu()
+    pm, pv = orc.posterior(x, y, h["mean"], noise, h["w"], h["mu"].reshape(4, 1), h["v"].reshape(4, 1), xs, h["mean"])
+    assert mean.shape == (10000,) and bool(torch.isfinite(mean).all()) and bool(torch.isfinite(var).all())
+    # posterior mean |values| ~ 1, latent variances 1e-4 .. 1: both to 1e-8 absolute (observed ~1e-12)
+    assert float((mean - pm).abs().max()) < 1e-8, float((mean - pm).abs().max())
+    assert float((var - pv).abs().max()) < 1e-8, float((var - pv).abs().max())
+    assert float(var.min()) > -1e-10                              # a variance: no cancellation below zero beyond round-off
+
+
 def test_train_loop_mirrors_reference_results(dev):
     """pgmuvi.trainers.train semantics (reference tests/test_2d_integration.py:110,131-135:
     loss list non-empty and decreasing)."""

@@ -187,3 +187,19 @@ def test_chains_sharded_over_two_gloo_ranks_equal_one_process():
         assert f.shape == (3, 6, 1, 1, 1)
         assert np.allclose(f, one["covar_module.mixture_means_prior"], rtol=1e-12, atol=0)
         assert np.array_equal(nl, one["_diagnostics"]["n_leapfrog"])
+
+
+def test_effective_sample_size_on_known_chains():
+    """Independent draws count (almost) fully, an AR(1) chain with coefficient 0.9 counts (1 - 0.9) / (1 + 0.9) of its length."""
+    import numpy as np
+    from pgmuvi_amd import mcmc
+    rng = np.random.default_rng(0)
+    iid = rng.standard_normal((4, 1000, 2))
+    ess = mcmc.effective_sample_size(iid)
+    assert ess.shape == (2,) and (ess > 2500).all() and (ess < 6000).all()
+    z = np.zeros((4, 1000))
+    for c in range(4):
+        for t in range(1, 1000):
+            z[c, t] = 0.9 * z[c, t - 1] + rng.standard_normal()
+    ar = float(mcmc.effective_sample_size(z[:, :, None])[0])
+    assert 120 < ar < 350, ar                                     # 4000 * 0.0526 = 210

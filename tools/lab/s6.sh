@@ -1,0 +1,11 @@
+mkdir -p gpurun_out/s6
+o=gpurun_out/s6/ab.txt
+for v in base staged fillstaged fill6; do
+  if [ "$v" = base ]; then d=pgmuvi_amd; else d=tools/variants/$v; fi
+  echo "== $v" >> $o
+  for a in "4096 50 1" "2048 50 1" "1024 100 1" "3000 50 1" "2048 20 1 4 64" "4096 5 1 4 64" "2048 50 1 4 8" "4096 10 1 4 8" "8192 5 1" "256 50 1 4 1024"; do
+    LD_LIBRARY_PATH=$PWD/$d:$LD_LIBRARY_PATH timeout -k 5 120 tools/evalloop $a >> $o 2>&1
+  done
+done
+tools/selftest > gpurun_out/s6/selftest.txt 2>&1; echo "selftest rc=$?" >> gpurun_out/s6/selftest.txt
+timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/s6/pytest.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/s6/pytest.txt
