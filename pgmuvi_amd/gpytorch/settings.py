@@ -149,3 +149,11 @@ class check_cholesky_info(_feature_flag):
     ``trainers.py:184``) and applies GPyTorch's jitter-retry policy; when off a failed
     factorisation surfaces as a NaN loss instead."""
     _default = True
+
+
+class defer_cholesky_check(_feature_flag):
+    """pgmuvi_amd extension (used by ``pgmuvi_amd.trainers.train``): when on, ``mll(output, y)`` does not wait for the
+    factorisation status; the caller asks for it with ``pgmuvi_amd.mll_function.take_deferred_failure()`` once it has queued
+    its own host work (``loss.backward()``) behind the evaluation, and repeats the evaluation in the ordinary mode -- where
+    the jitter-retry policy applies -- if it failed."""
+    _default = False

@@ -28,11 +28,27 @@ def _failed(out) -> bool:
     return bool((info != 0).any()) if status is None else status
 
 
+_deferred = []          # evaluations whose factorisation status nobody has asked for yet (settings.defer_cholesky_check)
+
+
+def take_deferred_failure() -> bool:
+    """Did any evaluation run under ``settings.defer_cholesky_check`` since the last call fail to factor?  Waits for the
+    factorisation sweep of those evaluations only (by the time a training loop asks -- after ``loss.backward()`` -- it is
+    usually over)."""
+    failed = False
+    while _deferred:
+        failed = _failed(_deferred.pop()) or failed
+    return failed
+
+
 def _evaluate(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, need_grad):
     """Runs the HIP evaluation with GPyTorch's psd_safe_cholesky retry policy:
     jitter 0 first, then cholesky_jitter * 10**i for i < cholesky_max_tries."""
     out = _hip.mll_value_grad(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, 0.0, need_grad)
     if settings.check_cholesky_info.off():
+        return out, 0.0
+    if settings.defer_cholesky_check.on():
+        _deferred.append(out)
         return out, 0.0
     if not _failed(out):
         return out, 0.0
@@ -142,7 +158,12 @@ def _evaluate_dense(A, r, need_grad):
 def _evaluate_kernel(x, y, mean, noise_vec, noise_scalar, program, theta, need_grad):
     """The fused generic-kernel evaluation with the same jitter-retry policy as ``_evaluate``."""
     out = _hip.mll_kernel_value_grad(x, y, mean, noise_vec, noise_scalar, program, theta, 0.0, need_grad)
-    if settings.check_cholesky_info.off() or not _failed(out):
+    if settings.check_cholesky_info.off():
+        return out, 0.0
+    if settings.defer_cholesky_check.on():
+        _deferred.append(out)
+        return out, 0.0
+    if not _failed(out):
         return out, 0.0
     if bool(torch.isnan(y).any()) or bool(torch.isnan(theta).any()):
         raise NanError("cholesky: NaN in the inputs of the marginal log likelihood.")

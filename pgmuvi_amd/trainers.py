@@ -64,6 +64,9 @@ def _optimiser(optim, params, lr, eps, instances=True, **kw):
     raise ValueError("optim must be 'SGD', 'Adam', 'AdamW'" + (" or a torch optimiser instance" if instances else ""))
 
 
+_NP_DTYPE = {torch.float64: np.float64, torch.float32: np.float32, torch.float16: np.float16}
+
+
 class _Log:
     """The ``results`` dictionary of the reference's loop: "loss", "delta_loss" and one list per parameter -- with a
     Lightcurve the keys and (constrained) values of ``get_parameters()``, starting with the values before the first step;
@@ -84,6 +87,44 @@ class _Log:
         if self.results["loss"]:
             self.results["delta_loss"].append(value - self.results["loss"][-1])
         self.results["loss"].append(value)
+
+    def loss_and_parameters(self, loss):
+        """One iteration's entries, read from the device now (one ``.cpu()`` per tensor, as the reference's loop does,
+        ``trainers.py:184-195``)."""
+        self.loss(loss.cpu().detach().numpy())
+        self.parameters_now()
+
+    # -- the same through ONE asynchronous transfer per iteration (model mode on the GPU) --------------------------------
+    def snapshot(self, loss, slot):
+        """Queues the copy of this iteration's loss and raw parameters into pinned host buffer ``slot`` behind the
+        optimiser step; returns the handle ``take`` waits on."""
+        named = list(self.model.named_parameters())
+        pieces = [loss.detach().reshape(1)] + [p.detach().reshape(-1) for _, p in named]
+        flat = torch.cat([t if t.dtype is torch.float64 else t.double() for t in pieces])
+        if not hasattr(self, "_pinned"):
+            self._pinned = [torch.empty(flat.numel(), dtype=torch.float64).pin_memory() for _ in range(2)]
+        self._pinned[slot].copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev, slot, loss.dtype
+
+    def take(self, handle):
+        """Appends the entries of a snapshot (same values, dtypes and keys as ``loss_and_parameters``)."""
+        ev, slot, loss_dtype = handle
+        ev.synchronize()
+        host = self._pinned[slot].numpy()
+        self.loss(np.asarray(host[0], dtype=_NP_DTYPE[loss_dtype]))
+        off = 1
+        for name, p in self.model.named_parameters():
+            k = p.numel()
+            self.results[name].append(host[off:off + k].astype(_NP_DTYPE[p.dtype]).reshape(tuple(p.shape)))
+            off += k
+
+    def restore_last(self):
+        """The model goes back to the parameters of the last logged iteration."""
+        with torch.no_grad():
+            for name, p in self.model.named_parameters():
+                p.copy_(torch.as_tensor(self.results[name][-1]).to(p.device))
 
     def parameters_now(self):
         if self.lightcurve is not None:
@@ -116,16 +157,52 @@ def train(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=No
     likelihood.train()
     objective = _mll_objective(lossfn, likelihood, model)
     optimizer = _optimiser(optim, model.parameters(), lr, eps)
+    from . import mll_function
+    from .gpytorch import settings
     log = _Log(lightcurve, model)
+    mll_function.take_deferred_failure()                     # (nothing of an earlier caller's is left pending)
+    # Model mode on the GPU with an optimiser made here: the loop runs one iteration ahead of its own log.  The reference's
+    # loop copies the loss and every parameter to the host at the end of each iteration (five synchronising copies); here
+    # they leave in one asynchronous transfer that is read an iteration later, so the next evaluation is queued while the
+    # GPU still works on this one and the GPU never waits for the host.  Results, stop iteration and final parameters are
+    # the reference's: when the stop rule fires on iteration i (noticed during i + 1) the model is put back to iteration i's
+    # parameters -- which the log holds -- and iteration i + 1 is dropped.
+    ahead = lightcurve is None and isinstance(optim, str) and train_x.is_cuda
+    pending = None
     for i in _iterate(maxiter, progress):
         optimizer.zero_grad()
-        loss = -objective(model(train_x), train_y)
-        loss.backward()
+        # The evaluation is launched without waiting for its factorisation status; backward is queued behind it, and only
+        # then is the status asked for (by then the sweep is usually over: the host no longer idles through it, nor the
+        # GPU through the host's backward).  A failed factorisation -- rare -- repeats the iteration's forward and backward
+        # in the ordinary mode, where GPyTorch's jitter-retry policy (warning, NotPSDError) applies: the step is taken on
+        # the same value and gradients as without the deferral.
+        with settings.defer_cholesky_check(True):
+            loss = -objective(model(train_x), train_y)
+            loss.backward()
+        if mll_function.take_deferred_failure():
+            optimizer.zero_grad()
+            loss = -objective(model(train_x), train_y)
+            loss.backward()
         optimizer.step()
-        log.loss(loss.cpu().detach().numpy())
-        log.parameters_now()
-        if log.converged(i, miniter, stop, stopavg):
-            break
+        if not ahead:
+            log.loss_and_parameters(loss)
+            if log.converged(i, miniter, stop, stopavg):
+                break
+            continue
+        handle = log.snapshot(loss, i % 2)
+        if pending is not None:
+            log.take(pending)
+            if log.converged(i - 1, miniter, stop, stopavg):
+                log.restore_last()
+                handle = None
+                break
+        pending = handle
+    else:
+        handle = pending
+    if ahead and handle is not None:                         # the last iteration's entries (no stop before it)
+        log.take(handle)
+        # (its own stop test only prints: there is no later iteration to leave out)
+        log.converged(len(log.results["loss"]) - 1, miniter, stop, stopavg)
     return log.results
 
 
