@@ -86,6 +86,7 @@ struct pgm_ws {
   double* pred_buf;      // right-hand sides of pgm_predict_f64 (grown on demand)
   size_t pred_bytes;
   int panel;             // block rows per delayed trailing update (k-depth = panel*128); 0 = fused sweep
+  int inleft;            // batches: left-looking inside a panel (run_sweep)
   int strips_min;        // batches: k_trsm_strips from this many block rows x light curves on
   int strips;            // batches: row solve by k_trsm_strips
   int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on

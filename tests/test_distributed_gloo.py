@@ -110,7 +110,7 @@ def test_strong_scaling_step_is_independent_of_the_partition(total, world):
         lo, hi = shard_bounds(total, rank, world)
         if nloc:
             assert torch.equal(gmu, ref["g_mu"][lo:hi])
-    assert default_chunk(2048) == 64 and 1 <= default_chunk(16384) < 8
+    assert default_chunk(2048) == 512 and default_chunk(4096) == 256 and 1 <= default_chunk(16384) <= 16
 
 
 def test_partitioning_rules():

@@ -14,8 +14,8 @@
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int PD, int NW>   // NW wavefronts per workgroup: 4 (2x2 of 64x64) or 8 (4x2 of 32(m)x64(n))
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_direct(const double* A, int64_t ld, int nkb, int cold, int64_t rows, double* out) {
+template <int PD, int NW, int WPS = (NW == 4 ? 2 : 1), bool RMW = false>   // NW wavefronts per workgroup: 4 (2x2 of 64x64) or 8 (4x2 of 32(m)x64(n)); RMW: the C tile is read first and written last
+__global__ __launch_bounds__(NW * 64, WPS) void k_direct(const double* A, int64_t ld, int nkb, int cold, int64_t rows, double* out, double* Ct = nullptr) {
   constexpr int TM = (NW == 4) ? 4 : 2, TN = 4;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = (wave / 2) * (16 * TM), n0 = (wave % 2) * 64;
@@ -29,10 +29,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_direct(const doubl
   const int voa = (g * (int)ld + m0 + TM * i) * 8, vob = (g * (int)ld + n0 + TN * i) * 8;
   const int step = 4 * (int)ld * 8;                              // bytes per k-step
   v4d acc[TM][TN];
+  double* cbase = RMW ? Ct + (int64_t)blockIdx.x * 128 * 128 : nullptr;     // (a private, contiguous 128x128 tile per workgroup)
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = v4d{0, 0, 0, 0};
+  if (RMW) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* q = cbase + (m0 + TM * (g + 4 * r) + ti) * 128 + n0 + TN * i;
+        const v2d x0 = *reinterpret_cast<const v2d*>(q), x1 = *reinterpret_cast<const v2d*>(q + 2);
+        acc[ti][0][r] = -x0[0]; acc[ti][1][r] = -x0[1]; acc[ti][2][r] = -x1[0]; acc[ti][3][r] = -x1[1];
+      }
+  }
   double a[PD][TM], b[PD][TN];
   auto load = [&](int u, int ks) {
     const int so = ks * step;
@@ -60,6 +71,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_direct(const doubl
         for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][ti], b[u][tj], acc[ti][tj], 0, 0, 0);
       if (ks + u + PD < nks) load(u, ks + u + PD);
     }
+  }
+  if (RMW) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* q = cbase + (m0 + TM * (g + 4 * r) + ti) * 128 + n0 + TN * i;
+        *reinterpret_cast<v2d*>(q) = v2d{-acc[ti][0][r], -acc[ti][1][r]}; *reinterpret_cast<v2d*>(q + 2) = v2d{-acc[ti][2][r], -acc[ti][3][r]};
+      }
+    return;
   }
   double s = 0.0;
 #pragma unroll
@@ -140,5 +161,15 @@ int main() {
       snprintf(name, sizeof name, "%s direct 8 waves 32x64, PD 16, 1 WG/CU (2 waves/SIMD)", tag);
       timeit(name, [&] { hipLaunchKernelGGL((k_direct<16, 8>), dim3(256), dim3(512), 0, 0, A, ld, nkb, cold, rows, out); }, 256, nkb);
     }
+  {  // trailing-update shape: private C tile read first and written last, operands cold, k-depth 512 / 1024; 2 or 3 workgroups per CU
+    double* Ct; hipMalloc(&Ct, sizeof(double) * 128 * 128 * 4096); hipMemset(Ct, 0, sizeof(double) * 128 * 128 * 4096);
+    for (int nkb : {1, 2, 4, 8}) {
+      timeit("COLD + C tile RMW, direct PD 4, 2 WG/CU, 2048 tiles", [&] { hipLaunchKernelGGL((k_direct<4, 4, 2, true>), dim3(2048), dim3(256), 0, 0, A, ld, nkb, 1, rows, out, Ct); }, 2048, nkb);
+      timeit("COLD + C tile RMW, direct PD 2, 2 WG/CU, 2048 tiles", [&] { hipLaunchKernelGGL((k_direct<2, 4, 2, true>), dim3(2048), dim3(256), 0, 0, A, ld, nkb, 1, rows, out, Ct); }, 2048, nkb);
+      timeit("COLD + C tile RMW, direct PD 2, 3 WG/CU, 2048 tiles", [&] { hipLaunchKernelGGL((k_direct<2, 4, 3, true>), dim3(2048), dim3(256), 0, 0, A, ld, nkb, 1, rows, out, Ct); }, 2048, nkb);
+      timeit("COLD + C tile RMW, direct PD 4, 3 WG/CU (spills?), 2048 tiles", [&] { hipLaunchKernelGGL((k_direct<4, 4, 3, true>), dim3(2048), dim3(256), 0, 0, A, ld, nkb, 1, rows, out, Ct); }, 2048, nkb);
+      timeit("COLD no RMW, direct PD 4, 2 WG/CU, 2048 tiles", [&] { hipLaunchKernelGGL((k_direct<4, 4, 2, false>), dim3(2048), dim3(256), 0, 0, A, ld, nkb, 1, rows, out, Ct); }, 2048, nkb);
+    }
+  }
   return 0;
 }
