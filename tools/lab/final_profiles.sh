@@ -1,0 +1,15 @@
+# the round's evidence on the final library: kernel stats, PMC traffic, MfmaUtil, timeline per workload (tools/profile.sh), and
+# the kernel statistics of bench.py itself
+set -e
+cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+bash tools/profile.sh single_n4096 4096 5 1
+bash tools/profile.sh batch512_n2048 2048 2 1 4 512
+bash tools/profile.sh cfg4_n8192_d2 8192 3 1 3 1 2
+bash tools/profile.sh cfg5_tick_8x2048 2048 5 1 4 8
+bash tools/profile.sh batch256_n4096 4096 1 1 4 256
+mkdir -p gpurun_out/prof_bench
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o stats -- python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu > gpurun_out/prof_bench/bench_line.json 2> gpurun_out/prof_bench/bench.err
+s=$(find gpurun_out/prof_bench -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_bench/kernel_stats.csv
+find gpurun_out/prof_bench -name '*_kernel_trace.csv' -delete
+sha256sum pgmuvi_amd/libpgmuvi_hip.so > gpurun_out/prof_lib_sha.txt
