@@ -18,13 +18,14 @@ namespace {
 constexpr int LS_THREADS = 256;
 constexpr int LS_CHUNK = 512;
 
-// scratch layout per light curve: w[n], wy[n], yy
+// scratch layout per light curve: w[n], wy[n], yy (light curve b at scratch + b * stride: 2 n + 1 for the exact sums, the FFT form's
+// longer record for the fast path)
 __global__ __launch_bounds__(LS_THREADS) void k_ls_prepare(const double* __restrict__ y, const double* __restrict__ dy,
-                                                           int64_t n, double* __restrict__ scratch) {
+                                                           int64_t n, double* __restrict__ scratch, int64_t stride) {
   const int b = blockIdx.x, t = threadIdx.x;
   const double* yb = y + (int64_t)b * n;
   const double* db = dy ? dy + (int64_t)b * n : nullptr;
-  double* w = scratch + (int64_t)b * (2 * n + 1);
+  double* w = scratch + (int64_t)b * stride;
   double* wy = w + n;
   __shared__ double red[LS_THREADS];
   auto reduce = [&](double v) {
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_lomb_scargle(const double* __res
 // nfft = 2^ceil(log2(oversampling nf)) points with 4-point Lagrange weights (astropy's defaults: oversampling 5, M = 4).
 // Kernels: prepare (weights, centring, t_min) -> spread (atomic adds into the three grids) -> log2(nfft) Stockham radix-2
 // passes (three transforms per launch) -> combine.  Scratch per light curve: [w n | wy n | yy, tmin | 6 nfft complex].
+// Every step is ONE launch for the whole batch (batch on gridDim.z / gridDim.x); the scratch is zeroed with one memset.
+// The spread adds with fp64 atomics, so two runs agree to round-off only (the exact-sum path is bit-reproducible).
 // ---------------------------------------------------------------------------------------------------------------
 typedef double2 cplx;
 
@@ -116,11 +119,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_ls_tmin(const double* __restrict
   const int b = blockIdx.x, t = threadIdx.x;
   __shared__ double red[LS_THREADS];
   double m = 1e300;
-  for (int64_t i = t; i < n; i += LS_THREADS) m = fmin(m, tt[(int64_t)b * n + i]);
+  for (int64_t i = t; i < n; i += LS_THREADS) { const double v = tt[(int64_t)b * n + i]; if (isfinite(v)) m = fmin(m, v); }   // (a NaN or an infinity among the times does not become the origin)
   red[t] = m;
   __syncthreads();
   for (int s = LS_THREADS / 2; s > 0; s >>= 1) { if (t < s) red[t] = fmin(red[t], red[t + s]); __syncthreads(); }
-  if (t == 0) scratch[(int64_t)b * stride + 2 * n + 1] = red[0];
+  if (t == 0) scratch[(int64_t)b * stride + 2 * n + 1] = (red[0] < 1e300) ? red[0] : 0.0;
 }
 
 // which = blockIdx.y: 0: h = w y, frequencies f;  1: h = w, frequencies 2 f;  2: h = w, frequencies f
@@ -233,13 +236,11 @@ extern "C" int pgm_lomb_scargle_fast_f64(const double* t, const double* y, const
   const int64_t nfft = ls_fast_nfft(nf, oversampling);
   const int64_t stride = ls_fast_stride(n, nfft);
   hipStream_t st = (hipStream_t)stream;
-  // weights, centred w y and yy: the exact path's prepare kernel on this layout (its scratch stride is a parameter there)
-  for (int b = 0; b < batch; ++b)
-    hipLaunchKernelGGL(k_ls_prepare, dim3(1), dim3(LS_THREADS), 0, st, y + (int64_t)b * n, dy ? dy + (int64_t)b * n : nullptr, n,
-                       scratch + (int64_t)b * stride);
+  // the three grids start at zero (one memset of the whole scratch, records included), then weights, centred w y and yy by the
+  // exact path's prepare kernel on this layout, one workgroup per light curve
+  hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)batch * (size_t)stride, st);
+  hipLaunchKernelGGL(k_ls_prepare, dim3(batch), dim3(LS_THREADS), 0, st, y, dy, n, scratch, stride);
   hipLaunchKernelGGL(k_ls_tmin, dim3(batch), dim3(LS_THREADS), 0, st, t, n, scratch, stride);
-  for (int b = 0; b < batch; ++b)
-    hipMemsetAsync(scratch + (int64_t)b * stride + 2 * n + 2, 0, sizeof(double) * 12 * (size_t)nfft, st);
   hipLaunchKernelGGL(k_ls_spread, dim3((unsigned)((n + LS_THREADS - 1) / LS_THREADS), 3, batch), dim3(LS_THREADS), 0, st,
                      t, scratch, n, stride, f0, df, nfft);
   int from_pong = 0;
@@ -265,7 +266,7 @@ extern "C" int pgm_lomb_scargle_f64(const double* t, const double* y, const doub
   if (!scratch) return -9;
   if (!power) return -10;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ls_prepare, dim3(batch), dim3(LS_THREADS), 0, st, y, dy, n, scratch);
+  hipLaunchKernelGGL(k_ls_prepare, dim3(batch), dim3(LS_THREADS), 0, st, y, dy, n, scratch, 2 * n + 1);
   hipLaunchKernelGGL(k_lomb_scargle, dim3((unsigned)((nf + LS_THREADS - 1) / LS_THREADS), 1, batch), dim3(LS_THREADS), 0, st,
                      t, scratch, n, freq, nf, fit_mean, power);
   return hipGetLastError() == hipSuccess ? 0 : -99;
