@@ -1326,6 +1326,47 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
             assert _rel(outs["default"][f"g_{p}"].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
+@pytest.mark.parametrize("need_grad", [True, False])
+def test_batch_schedule_of_round_3_is_bit_for_bit_round_2s(dev, monkeypatch, need_grad):
+    """A batch big enough for the panel sweep's round-3 kernels (32 x N=1100: 9 block rows each, 288 in all) -- the strip
+    kernel for the row solve (U_kk^-1 resident in LDS, the zero half of the triangular factor skipped) and the left-looking
+    updates inside a panel -- against the slab kernel and the one-row-at-a-time in-panel updates of round 2: the MFMAs that
+    are left out add exact zeros, every tile still receives its sources in ascending order, the forward-substitution sums keep
+    their order, so every output is the same bit for bit; and each light curve's value equals its single evaluation's."""
+    B, n = 32, 1100
+    xs, ys, ns, ws, mus, vs, means = [], [], [], [], [], [], []
+    for i in range(B):
+        (t, y, e), per = syn.cfg3_lightcurve(40 + i, n_obs=n)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        xs.append(t.double().reshape(n, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+        ws.append(h["w"]); mus.append(h["mu"].reshape(4, 1)); vs.append(h["v"].reshape(4, 1)); means.append(h["mean"].expand(n))
+    st = lambda L: torch.stack(L).to(dev)
+    args = (st(xs), st(ys), st(means), st(ns), st(ws), st(mus), st(vs))
+    keys = ("mll", "g_w", "g_mu", "g_v", "g_noise", "g_mean") if need_grad else ("mll",)
+    outs = {}
+    for name, env in (("round3", {}), ("round2", {"PGM_STRIPS": "0", "PGM_INLEFT": "0"})):
+        _hip.release_workspaces()
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        o = evaluate_batch(*args, need_grad=need_grad)
+        torch.cuda.synchronize()
+        outs[name] = {k: o[k].clone().cpu() for k in keys + ("info",)}
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    _hip.release_workspaces()
+    assert int(outs["round3"]["info"].abs().max()) == 0
+    for k in keys:
+        assert torch.equal(outs["round3"][k], outs["round2"][k]), k
+    for i in (0, 7, 31):
+        single = _hip_eval(dev, xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
+        assert float(single["mll"]) == float(outs["round3"]["mll"][i])
+        val, gr = orc.mll_value_grad_closed_form(xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
+        assert abs(float(val) - float(outs["round3"]["mll"][i])) < MLL_TOL
+        if need_grad:
+            for p_ in ("w", "mu", "v"):
+                assert _rel(outs["round3"][f"g_{p_}"][i].reshape(-1), gr[p_].reshape(-1)) < GRAD_RTOL, p_
+
+
 def test_windowed_sweep_of_big_single_curves_equals_plain_panels(dev, monkeypatch):
     """41..64 block rows, one light curve: the rows of the current window ride the fused chain (update tiles as fillers of
     the diagonal-block launches), the rows beyond it get one deep update per window.  Same factor, hence the same value bit
