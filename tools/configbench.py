@@ -14,7 +14,7 @@ def timeit(f, reps):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
 
-for B in (8, 64):
+for B in (8, 64, 512):
     xs, ys, ns, ws_, mus, vs, ms = [], [], [], [], [], [], []
     for i in range(B):
         (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=2048)
@@ -46,6 +46,7 @@ for B, nn in ((2048, 89), (1024, 256)):
     h = syn.cfg_hypers(3, ys[0])
     w = h["w"].expand(B, 4).contiguous().to(dev); mu = h["mu"].reshape(1, 4, 1).expand(B, 4, 1).contiguous().to(dev); v = h["v"].reshape(1, 4, 1).expand(B, 4, 1).contiguous().to(dev)
     m = torch.zeros(B, nn, dtype=D, device=dev)
-    dt = timeit(lambda: _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True), 5)
+    torch.cuda.synchronize()
+    dt = timeit(lambda: _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True), 50)          # (short calls: many repetitions)
     print(f"many short light curves: {B} x N={nn} per launch set: {dt*1e3:.2f} ms = {B/dt:.0f} evals/s")
     _hip.release_workspaces()
