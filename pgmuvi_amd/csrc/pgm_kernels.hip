@@ -287,8 +287,32 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return __builtin_fma(0.5 * y, e, y);
 }
 
+// The diagonal block on ONE workgroup of 16 wavefronts (round 3 form).  The 128x128 block is 8x8 sub-blocks of 16x16; step s
+// factors sub-block (s, s) on the chain wave, solves block row s and applies it to everything behind it -- the same sweep one
+// level down.  Every sub-block lives in the REGISTERS of one worker wavefront for the whole kernel, in the f64 MFMA C layout
+// (lane (g, n): rows g + 4r of column n) -- which is also the A- and the B-fragment layout of the products it enters later,
+// so a block is read from memory once, its accumulator never travels, and only FINISHED block rows go through LDS (as the
+// operands of the others).  Before: all sub-blocks in LDS, read and written by every update (270 KB of LDS traffic per step).
+//   wave 0            the chain: potrf of (s+1, s+1) while the workers apply block row s; it also solves its own copy of
+//                     (s, s+1) and applies it to (s+1, s+1), so that it never waits for more than the two barriers of a step
+//   waves 4, 8, 12    its SIMD-mates (a wavefront w runs on SIMD w % 4) keep the books / store V_ss: no MFMA on the chain's SIMD
+//   the other twelve  workers; sub-block (i, j) belongs to DIAG_OWN[worker][slot] -- found by search: the 7 blocks of a row on
+//                     7 different workers, and per step at most 3, 3, 3, 3, 2, 2, 1 active blocks per worker (the lower bound)
+// The arithmetic per sub-block is what it always was (4 chained MFMAs per update or solve, steps in order): results are bit
+// for bit those of rounds 1-2.
+constexpr int DIAG_WORKERS = 12, DIAG_SLOTS = 6;
+__constant__ unsigned char DIAG_OWN[DIAG_WORKERS][8] = {      // (i << 4) | j, 0xff: none
+  {0x02, 0x36, 0x43, 0x44, 0x55, 0x64, 0xff, 0xff}, {0x03, 0x13, 0x34, 0x51, 0x65, 0x66, 0xff, 0xff},
+  {0x04, 0x16, 0x24, 0x31, 0x56, 0x62, 0xff, 0xff}, {0x20, 0x35, 0x42, 0x52, 0x74, 0xff, 0xff, 0xff},
+  {0x17, 0x27, 0x60, 0x71, 0xff, 0xff, 0xff, 0xff}, {0x05, 0x15, 0x37, 0x41, 0x50, 0x75, 0xff, 0xff},
+  {0x07, 0x33, 0x47, 0x67, 0x76, 0xff, 0xff, 0xff}, {0x22, 0x23, 0x32, 0x57, 0x73, 0xff, 0xff, 0xff},
+  {0x14, 0x25, 0x40, 0x63, 0x72, 0xff, 0xff, 0xff}, {0x01, 0x26, 0x45, 0x54, 0x70, 0xff, 0xff, 0xff},
+  {0x06, 0x10, 0x46, 0x61, 0xff, 0xff, 0xff, 0xff}, {0x12, 0x21, 0x30, 0x53, 0x77, 0xff, 0xff, 0xff}};
+
 struct DiagCtx {
-  double* M;        // LDS image [NB][PM]
+  double* prow;     // LDS [2][8][256]: the solved block row of step s (parity s & 1), sub-block j row-major = fragment r at [64 r + lane]
+  double* dg;       // LDS [8][256]: diagonal sub-block i with the steps < i-1 applied (its owner's last word; the chain applies step i-1)
+  double* sup;      // LDS [8][256]: sub-block (i, i+1) with the steps < i applied, unsolved (the chain solves its own copy)
   double* uiS;      // uiS[k*16+m] = V_ss[m][k]
   double* udg;      // U_pp (square roots of the pivots)
   double* pbuf;     // [4][32] mini-panel exchange buffer
@@ -296,8 +320,6 @@ struct DiagCtx {
   int64_t ld;
   double* Dinv0;    // global Uinv  [p][m]
   double* Dinv1;    // global Uinv^T = V [k][n]
-  int* info;
-  int kbase;        // k * NB (for the failure index)
   double* dump;     // LDS scratch (one slot per lane) that absorbs predicated-off stores
 };
 
@@ -306,29 +328,34 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// (a) one wavefront: Cholesky of the 16x16 sub-block s plus its inverse factor.
+__device__ __forceinline__ v4d diag_load_block(const DiagCtx& c, int i, int j, int lane) {
+  const int g = lane >> 4, n = lane & 15;
+  v4d v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = c.Akk[(int64_t)(i * DB + g + 4 * r) * c.ld + j * DB + n];
+  return v;
+}
+
+// (a) one wavefront: Cholesky of the 16x16 sub-block s (`ua`, C layout) plus its inverse factor.
 // The block and an identity (whose image under the same row operations is V = u^-T)
 // are held in the f64 MFMA C layout (lane (g, n) = rows g+4r of column n).  Pivots go
 // in mini-panels of 4 rows: the panel is exchanged through LDS so that every lane
 // holds the 4 panel rows of its column, is factored with uniform multipliers
 // (v_readlane), and the rank-4 trailing update of both images is one MFMA each:
 //   acc -= P^T P  ==  mfma(-row, row, acc)   (the panel row IS the A and B fragment).
-// `pre`: the sub-block's values already in registers (C layout) -- sub-block 0 comes straight from global memory, ahead of
-// the rest of the block's image.
-__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, const v4d* pre = nullptr) {
+// Leaves V_ss in block s of the block row's LDS image (zero above its diagonal by construction: the identity's image
+// only ever takes multiples of earlier rows), its transpose in uiS, the pivots' square roots in udg.
+template <bool BARRIER = false>
+__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, v4d ua) {
   const int g = lane >> 4, n = lane & 15;
-  double* Mb = c.M + (s * DB) * PM + s * DB;
   double* pbuf = c.pbuf;                      // [4][32]
-  v4d ua, va;                                 // A image, identity image (C layout)
+  v4d va;                                     // identity image (C layout)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    ua[r] = pre ? (*pre)[r] : Mb[(g + 4 * r) * PM + n];
-    va[r] = (g + 4 * r == n) ? 1.0 : 0.0;
-  }
+  for (int r = 0; r < 4; ++r) va[r] = (g + 4 * r == n) ? 1.0 : 0.0;
   double fa[4], fb[4];
   // No test inside the pivot chain: a non-positive pivot turns into NaN (rsq of a negative) or
   // inf and poisons everything after it; the first bad diagonal entry is located once, after
-  // the block is finished (k_diag tail), which keeps ~5 instructions per pivot off the chain.
+  // the block is finished (bookkeeping wave), which keeps ~5 instructions per pivot off the chain.
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     pbuf[g * 32 + n] = ua[m];
@@ -359,105 +386,157 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, 
       ua = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, ra, ua, 0, 0, 0);
       va = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, rb, va, 0, 0, 0);
     }
+    // The second barrier of the previous step ("block row s-1 is in LDS") is nothing this wavefront waits for -- it only has to
+    // be counted: met here, one mini-panel into the factorisation, the workers' row solves are over and the chain never idles at it.
+    if (BARRIER && m == 0) lds_barrier();
   }
   double* mydump = c.dump + lane;
+  double* vss = c.prow + (s & 1) * (NB / DB) * DB * DB + s * DB * DB + lane;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = g + 4 * r;
-    Mb[i * PM + n] = (n > i) ? fa[r] : fb[r];     // u strictly above the diagonal, V on and below
-    c.uiS[n * DB + i] = fb[r];                     // uiS[k*16+m] = V[m][k]; V is 0 above its diagonal
+    vss[64 * r] = fb[r];                           // V_ss, row-major (U_ss above its diagonal is needed by nobody)
+    c.uiS[n * DB + i] = fb[r];                     // uiS[k*16+m] = V[m][k]
     double* dst = (n == i) ? (c.udg + s * DB + i) : mydump;
     *dst = fa[r];                                  // U_ii = sqrt(pivot)
   }
 }
 
-// (b) X(s,j) <- V_ss X(s,j), in place.  Finished V blocks leave for global memory at once, from
-// the wave that made them: a CU retires only ~10 B/clk of stores, so the 130 KB of inverse images
-// must trickle out beside the arithmetic.  U_kk itself is never read again (later steps use U_kj,
-// j > k, and the inverse images) and is not written back.
-__device__ __forceinline__ void diag_rowsolve(const DiagCtx& c, int s, int j, int lane) {
+// (b) X <- V_ss X for a sub-block of block row s held in the C layout (= the B-fragment layout: k-step r is x[r])
+__device__ __forceinline__ v4d diag_solve(const DiagCtx& c, const v4d& x, int lane) {
   const int kq = lane >> 4, n = lane & 15;
-  double b[4];
+  double a[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) b[r] = c.M[(s * DB + 4 * r + kq) * PM + j * DB + n];
+  for (int r = 0; r < 4; ++r) a[r] = c.uiS[(4 * r + kq) * DB + n];
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c.uiS[(4 * r + kq) * DB + n], b[r], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], x[r], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ void diag_put(double* dst, const v4d& v, int lane) {      // one sub-block into an LDS image
 #pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) {
-    const int row = s * DB + kq + 4 * r2, colg = j * DB + n;
-    c.M[row * PM + colg] = acc[r2];
+  for (int r = 0; r < 4; ++r) dst[64 * r + lane] = v[r];
+}
+__device__ __forceinline__ v4d diag_get(const double* src, int lane) {
+  v4d v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = src[64 * r + lane];
+  return v;
+}
+
+// finished block (s, j), j <= s, of V = U^-T: to both inverse images, straight from the registers.  A CU retires only ~10 B/clk
+// of stores: they are issued right behind the step that finished the block and drain beside the arithmetic of the next ones.
+// (Measured and not kept: the transposed image as whole 128-byte row segments, X^T made by four MFMAs against an identity --
+//  a quarter of the write requests, no faster: the bytes are what the write path counts.)
+// which: 1 = the row-major image, 2 = the transposed one, 3 = both.  (The zero triangles are cleared once, at workspace creation.)
+__device__ __forceinline__ void diag_store_v(const DiagCtx& c, int s, int j, const v4d& v, int lane, int which = 3) {
+  const int kq = lane >> 4, n = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = kq + 4 * r;
+    if (j < s || n <= i) {
+      if (which & 1) c.Dinv1[(s * DB + i) * NB + j * DB + n] = v[r];
+      if (which & 2) c.Dinv0[(j * DB + n) * NB + s * DB + i] = v[r];
+    }
   }
 }
 
-// block (s, j), j <= s, of V = U^-T is final: write it to both inverse images.  Called by worker
-// waves AFTER their trailing sub-blocks of the step, so that the (slow: a CU retires ~10 B/clk)
-// stores overlap the chain wave's next factorisation instead of sitting in front of a barrier.
-__device__ __forceinline__ void diag_store_vblock(const DiagCtx& c, int s, int j, int lane) {
-  const int kq = lane >> 4, n = lane & 15;
+// a worker wavefront: its sub-blocks through all steps.  (The slot table stays packed in one scalar register pair and is
+// decoded where it is used: two dozen wave-uniform integers kept live across the loop made the compiler spill scalars.)
+__device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, int nse) {
+  constexpr int NS = NB / DB;
+  const unsigned long long pack = *reinterpret_cast<const unsigned long long*>(DIAG_OWN[q]);
+#define SLOT_E(t) ((int)((pack >> (8 * (t))) & 0xffull))
+  v4d acc[DIAG_SLOTS];
 #pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) {                       // row-major image: lanes along the columns
-    const int i = kq + 4 * r2;
-    const double v = c.M[(s * DB + i) * PM + j * DB + n];
-    if (j < s || n <= i) c.Dinv1[(s * DB + i) * NB + j * DB + n] = v;
+  for (int t = 0; t < DIAG_SLOTS; ++t) {
+    const int e = SLOT_E(t), i = e >> 4, j = e & 15;
+    if (e != 0xff && i <= j) acc[t] = diag_load_block(c, i, j, lane);
+    else acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   }
+  for (int s = 0; s < nse; ++s) {
+    double* row = c.prow + (s & 1) * NS * DB * DB;
+    lds_barrier();                                             // V_ss of this step is in LDS
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {                          // transposed image: lanes along the rows
-    const int col = 4 * u + kq, i = n;
-    const double v = c.M[(s * DB + i) * PM + j * DB + col];
-    if (j < s || col <= i) c.Dinv0[(j * DB + col) * NB + s * DB + i] = v;
+    for (int t = 0; t < DIAG_SLOTS; ++t) {
+      const int e = SLOT_E(t), i = e >> 4, j = e & 15;
+      if (i == s && j != s) {                                  // my block of block row s: solve, publish
+        acc[t] = diag_solve(c, acc[t], lane);
+        diag_put(row + j * DB * DB, acc[t], lane);
+      }
+    }
+    lds_barrier();                                             // block row s is in LDS
+#pragma unroll
+    for (int t = 0; t < DIAG_SLOTS; ++t) {
+      const int e = SLOT_E(t), i = e >> 4, j = e & 15;
+      // steps whose block row is applied to this block: U (i < j): 0 .. i-1;  V (i > j): j .. i-1 (it is zero before);
+      // diagonal: 0 .. i-2 (the chain applies i-1 itself);  none: never
+      const int lo = (i > j) ? j : 0, hi = (e == 0xff) ? 0 : (i == j) ? i - 1 : i;
+      if (s >= lo && s < hi) {                                 // C(i,j) -= U(s,i)^T B(s,j);  B is U(s,j) (j>s), V(s,j) (j<s) or V_ss
+        const double* pa = row + i * DB * DB + lane;
+        const double* pb = row + j * DB * DB + lane;
+        double a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = -pa[64 * r]; b[r] = pb[64 * r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[r], acc[t], 0, 0, 0);
+        if (i == j && s == i - 2) diag_put(c.dg + i * DB * DB, acc[t], lane);              // over to the chain
+        if (j == i + 1 && s == i - 1) diag_put(c.sup + i * DB * DB, acc[t], lane);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DIAG_SLOTS; ++t) {
+      const int e = SLOT_E(t), i = e >> 4, j = e & 15;
+      if (i == s && j < s) diag_store_v(c, s, j, acc[t], lane);
+    }
   }
+  // block rows of identity padding (the last diagonal block of a light curve whose length is no multiple of 128): zero blocks
+#pragma unroll
+  for (int t = 0; t < DIAG_SLOTS; ++t) {
+    const int e = SLOT_E(t), i = e >> 4, j = e & 15;
+    if (i >= nse && i < NS && j < i) diag_store_v(c, i, j, acc[t], lane);
+  }
+#undef SLOT_E
 }
 
-// (c) C(i,j) <- C(i,j) - U(s,i)^T B(s,j);  B is U(s,j) (j>s), V(s,j) (j<s) or V_ss (j==s)
-__device__ __forceinline__ void diag_update(const DiagCtx& c, int s, int i, int j, int lane) {
-  const int kq = lane >> 4, n = lane & 15;
-  v4d acc;
+// the chain wavefront
+__device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse) {
+#ifdef PGM_DIAG_STAMPS
+  long long st_[40]; int sn_ = 0;
+#define STAMP() do { if (sn_ < 40) st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+  __builtin_amdgcn_s_setprio(3);
+  const v4d first = diag_load_block(c, 0, 0, lane);
+  v4d x = diag_load_block(c, 0, 1, lane);                     // what step 0 needs beyond (0, 0) comes straight from memory
+  v4d d = diag_load_block(c, 1, 1, lane);
+  diag_potrf16(c, 0, lane, first);
+  STAMP();
+  for (int s = 0; s < nse; ++s) {
+    lds_barrier();
+    STAMP();
+    if (s + 1 < nse) {
+      if (s > 0) { x = diag_get(c.sup + s * DB * DB, lane); d = diag_get(c.dg + (s + 1) * DB * DB, lane); }
+      const v4d u = diag_solve(c, x, lane);                    // U(s, s+1): the chain's own copy, the bits of its owner's
 #pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) acc[r2] = (j == s) ? 0.0 : c.M[(i * DB + kq + 4 * r2) * PM + j * DB + n];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int krow = s * DB + 4 * r + kq;
-    const double av = -c.M[krow * PM + i * DB + n];
-    double bv = c.M[krow * PM + j * DB + n];
-    if (j == s && n > 4 * r + kq) bv = 0.0;              // V_ss is lower triangular; above it sits u
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f64_16x16x4f64(-u[r], u[r], d, 0, 0, 0);
+    }
+    STAMP();
+    if (s + 1 < nse) diag_potrf16<true>(c, s + 1, lane, d);
+    else lds_barrier();
+    STAMP();
   }
-#pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) c.M[(i * DB + kq + 4 * r2) * PM + j * DB + n] = acc[r2];
-}
-
-// two independent trailing sub-blocks at once: their dependent MFMA chains interleave
-__device__ __forceinline__ void diag_update2(const DiagCtx& c, int s, int i1, int j1, int i2, int j2, int lane) {
-  const int kq = lane >> 4, n = lane & 15;
-  v4d acc1, acc2;
-#pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) {
-    acc1[r2] = (j1 == s) ? 0.0 : c.M[(i1 * DB + kq + 4 * r2) * PM + j1 * DB + n];
-    acc2[r2] = (j2 == s) ? 0.0 : c.M[(i2 * DB + kq + 4 * r2) * PM + j2 * DB + n];
+#ifdef PGM_DIAG_STAMPS
+  if (lane == 0 && blockIdx.z == 0) {      // clock ticks: start, potrf(0), then per step: barrier A, solve + update, potrf(s+1) with barrier B inside
+    printf("chain: ");
+    for (int q = 1; q < sn_; ++q) printf("%d ", (int)(st_[q] - st_[0]));
+    printf("\n");
   }
-  double a1[4], b1[4], a2[4], b2[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int krow = s * DB + 4 * r + kq;
-    a1[r] = -c.M[krow * PM + i1 * DB + n];
-    b1[r] = c.M[krow * PM + j1 * DB + n];
-    a2[r] = -c.M[krow * PM + i2 * DB + n];
-    b2[r] = c.M[krow * PM + j2 * DB + n];
-    if (j1 == s && n > 4 * r + kq) b1[r] = 0.0;
-    if (j2 == s && n > 4 * r + kq) b2[r] = 0.0;
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[r], b1[r], acc1, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[r], b2[r], acc2, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r2 = 0; r2 < 4; ++r2) {
-    c.M[(i1 * DB + kq + 4 * r2) * PM + j1 * DB + n] = acc1[r2];
-    c.M[(i2 * DB + kq + 4 * r2) * PM + j2 * DB + n] = acc2[r2];
-  }
+#endif
+#undef STAMP
 }
 
 // Filler role of the fused diagonal-block launch.  While workgroup 0 factors block k on one CU
@@ -628,12 +707,6 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
   __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], dump[64], pbuf[4 * 32];
-  constexpr int BLK_MAX = 40;                                  // >= trailing sub-blocks of a step (34 at s = 0)
-  __shared__ unsigned char blklist[(NB / DB) * BLK_MAX];       // (i << 4) | j per step, R blocks then T blocks
-  __shared__ int blkcnt[NB / DB];
-#ifdef PGM_DIAG_STAMPS
-  const long long entry_ = __builtin_amdgcn_s_memtime();
-#endif
   if (blockIdx.x > 0) {
     const int widx = (int)blockIdx.x - 1;
     if (widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, widx);
@@ -641,178 +714,112 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
     else early_inverse_tile<CfgFill>(P, M, P.tasks[task_lo + widx - nfill]);
     return;
   }
+#ifdef PGM_DIAG_STAMPS
+  const long long entry_ = __builtin_amdgcn_s_memtime();
+#endif
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: index math goes to the scalar unit
-  if (t >= 64 && t < 64 + NB / DB) {                           // thread 64 + s builds the list of step s (not on the chain wave)
-    const int s = t - 64, ns = NB / DB;
-    int cnt = 0;
-    for (int i = s + 1; i < ns; ++i) {
-      for (int j = 0; j <= s; ++j) blklist[s * BLK_MAX + cnt++] = (unsigned char)((i << 4) | j);
-      for (int j = i; j < ns; ++j) {
-        if (i == s + 1 && j == s + 1) continue;                // the next diagonal sub-block belongs to wave 0
-        blklist[s * BLK_MAX + cnt++] = (unsigned char)((i << 4) | j);
-      }
-    }
-    blkcnt[s] = cnt;
-  }
+  constexpr int NS = NB / DB;
   DiagCtx c;
-  c.M = M; c.uiS = uiS; c.udg = udg; c.dump = dump; c.pbuf = pbuf;
+  c.prow = M; c.dg = M + 2 * NS * DB * DB; c.sup = c.dg + NS * DB * DB;
+  c.uiS = uiS; c.udg = udg; c.dump = dump; c.pbuf = pbuf;
   c.Akk = P.A + b * P.sA + (int64_t)k * NB * P.ld + k * NB;
   c.ld = P.ld;
   c.Dinv0 = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
   c.Dinv1 = c.Dinv0 + NB * NB;
-  c.info = P.info + b;
-  c.kbase = k * NB;
-#ifdef PGM_DIAG_STAMPS
-  long long st_[40]; int sn_ = 0;
-#define STAMP() do { if (sn_ < 40) st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP() do {} while (0)
-#endif
-  STAMP();
-  // load the block (upper part is meaningful), fetch r_k.  The chain wave asks for sub-block (0, 0) FIRST and factors it while
-  // the rest of the image is still arriving (loads return in order: its wait covers those four loads only); everybody else
-  // leaves that sub-block out of the image.  The barrier at the top of step 0 is where the image is complete.
-  {  // all eight 16-B loads of a thread in flight at once (one memory round trip, not eight)
-    constexpr int NV = NB * NB / 2 / DIAG_THREADS;
-    v4d first = {0.0, 0.0, 0.0, 0.0};
-    if (wave == 0) {
-      __builtin_amdgcn_s_setprio(3);                           // the chain wave wins issue arbitration on its SIMD
-#pragma unroll
-      for (int r = 0; r < 4; ++r) first[r] = c.Akk[(int64_t)((lane >> 4) + 4 * r) * P.ld + (lane & 15)];
-    }
-    v2d tmp[NV];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
-      tmp[u] = *reinterpret_cast<const v2d*>(c.Akk + (int64_t)row * P.ld + c2);
-    }
-    const double rk = (t < NB) ? P.r[b * P.sVec + k * NB + t] : 0.0;
-    if (wave == 0) diag_potrf16(c, 0, lane, &first);
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = t + u * DIAG_THREADS, row = e / (NB / 2), c2 = (e % (NB / 2)) * 2;
-      if (row >= DB || c2 >= DB) *reinterpret_cast<v2d*>(M + row * PM + c2) = tmp[u];
-    }
-    if (t < NB) { rsv[t] = rk; alv[t] = 0.0; zsv[t] = 0.0; }
-  }   // (the zero triangles of the inverse images are cleared once, at workspace creation)
-  STAMP();
-  constexpr int NS = NB / DB;
   // The last block of a light curve whose length is no multiple of 128 ends in identity padding, decoupled from the data:
-  // the sub-block steps that would "factor" it are left out (N=89: 6 of 8 steps), its inverse images are stored as they are.
+  // the sub-block steps that would "factor" it are left out (N=89: 6 of 8 steps), its inverse images are zero blocks and identities.
   const int valid = (P.n - k * NB < NB) ? P.n - k * NB : NB;
   const int nse = __builtin_amdgcn_readfirstlane((valid + DB - 1) / DB);
-  double lgsum = 0.0;          // (bookkeeping wave)
-  int firstbad = -1;
-  for (int s = 0; s < nse; ++s) {
-    lds_barrier();
-    STAMP();
-#ifdef PGM_DIAG_STAMPS
-    const long long wb0_ = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- (b) block row s
-    if (wave < NS - 1) {
-      const int j = (wave < s) ? wave : wave + 1;
-      diag_rowsolve(c, s, j, lane);
-    } else if (wave == NS - 1) {                     // z_s = V_ss r_s (r_s is final since step s-1)
-      if (lane < DB) {
+  // Every wavefront meets the same two barriers per step: V_ss in LDS / block row s in LDS.
+  if (wave == 0) {
+    diag_chain(c, lane, nse);
+  } else if ((wave & 3) != 0) {
+    diag_worker(c, wave - 1 - (wave >> 2), lane, nse);
+  } else if (wave == 4) {
+    // bookkeeping: z_k = V_kk r_k by forward substitution beside the factorisation, alpha_k, log det, the pivot check
+    int* info = P.info + b;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rsv[lane + 64 * u] = P.r[b * P.sVec + k * NB + lane + 64 * u];
+      alv[lane + 64 * u] = 0.0;
+      zsv[lane + 64 * u] = 0.0;
+    }
+    double lgsum = 0.0;
+    int firstbad = -1;
+    for (int s = 0; s < nse; ++s) {
+      const double* row = c.prow + (s & 1) * NS * DB * DB;
+      lds_barrier();
+      if (lane < DB) {                                           // z_s = V_ss r_s (r_s is final since step s-1)
         double acc = 0.0;
 #pragma unroll
         for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
         zsv[s * DB + lane] = acc;
       }
-    }
-#ifdef PGM_DIAG_STAMPS
-    const long long wb1_ = __builtin_amdgcn_s_memtime();
-#endif
-    lds_barrier();
-    STAMP();
-#ifdef PGM_DIAG_STAMPS
-    const long long wc0_ = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- (c) trailing sub-blocks; wave 0 runs ahead on the next diagonal sub-block
-    if (wave == 0) {
-      if (s + 1 < nse) {
-        diag_update(c, s, s + 1, s + 1, lane);
-        STAMP();
-        diag_potrf16(c, s + 1, lane);
-        STAMP();
+      lds_barrier();
+      // forward substitution / alpha updates with block row s (2 columns per lane)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int colg = lane + 64 * u, jb = colg / DB;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < DB; ++m) acc += row[jb * DB * DB + m * DB + (colg - jb * DB)] * zsv[s * DB + m];   // (V_ss is zero above its diagonal)
+        if (jb > s) rsv[colg] -= acc; else alv[colg] += acc;
       }
-    } else {
-      if (wave == DIAG_WAVES - 1) {
-        // bookkeeping wave: forward substitution / alpha updates with block row s (2 columns per lane)
+      // ... and the block's share of log det A and the pivot check, one 16x16 sub-block per step, so that nothing is left after the last
+      {
+        const double u = udg[s * DB + (lane & 15)];
+        const unsigned long long badm = __ballot(!(u > 0.0 && u < 1e300)) & 0xffffull;
+        if (badm && firstbad < 0) firstbad = s * DB + (int)__builtin_ctzll(badm);
+        if (lane < DB) lgsum += 2.0 * log(u);
+      }
+      if (s == nse - 1) {                                 // z_k, alpha_k, log det, info: final now
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int colg = lane + 64 * u, jb = colg / DB;
-          double acc = 0.0;
-#pragma unroll
-          for (int m = 0; m < DB; ++m) {
-            double v = M[(s * DB + m) * PM + colg];
-            if (jb == s && (colg - s * DB) > m) v = 0.0;
-            acc += v * zsv[s * DB + m];
-          }
-          if (jb > s) rsv[colg] -= acc; else alv[colg] += acc;
+          P.z[b * P.sVec + k * NB + lane + 64 * u] = zsv[lane + 64 * u];
+          P.alpha[b * P.sVec + k * NB + lane + 64 * u] = alv[lane + 64 * u];
         }
-        // ... and the block's share of log det A and the pivot check ride here too, one 16x16 sub-block per
-        // step, so that nothing but stores is left after the last step
-        {
-          const double u = udg[s * DB + (lane & 15)];
-          const unsigned long long badm = __ballot(!(u > 0.0 && u < 1e300)) & 0xffffull;
-          if (badm && firstbad < 0) firstbad = s * DB + (int)__builtin_ctzll(badm);
-          if (lane < DB) lgsum += 2.0 * log(u);
+        const double tot = wave_sum(lgsum);
+        if (lane == 0) {
+          P.logdet[b * P.sLogdet + k] = tot;
+          // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
+          if (firstbad >= 0 && *info == 0) *info = k * NB + 1 + firstbad;
+          // the status is final with the last diagonal block: the host's copy (pgm_factorisation_status) is written here
+          if (k == P.nb - 1 && P.info_host) P.info_host[b] = *info;
         }
-        if (s == nse - 1) {                                 // z_k, alpha_k, log det, info: final now
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            P.z[b * P.sVec + k * NB + lane + 64 * u] = zsv[lane + 64 * u];
-            P.alpha[b * P.sVec + k * NB + lane + 64 * u] = alv[lane + 64 * u];
-          }
-          const double tot = wave_sum(lgsum);
-          if (lane == 0) {
-            P.logdet[b * P.sLogdet + k] = tot;
-            // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
-            if (firstbad >= 0 && *c.info == 0) *c.info = c.kbase + 1 + firstbad;
-            // the status is final with the last diagonal block: the host's copy (pgm_factorisation_status) is written here
-            if (k == P.nb - 1 && P.info_host) P.info_host[b] = *c.info;
-          }
-        }
-      }
-      // trailing sub-blocks of step s from the precomputed list (instruction issue, not MFMA, is
-      // what this kernel runs out of: no per-block decoding here), dealt over the worker waves
-      // 1..14 (the last wave keeps the books) and processed two at a time so that the dependent MFMA
-      // chains of a pair interleave
-      const int nblk = blkcnt[s];
-      const unsigned char* bl = blklist + s * BLK_MAX;
-      constexpr int NWORK = DIAG_WAVES - 2;
-      if (wave < DIAG_WAVES - 1) {
-        for (int idx = wave - 1; idx < nblk; idx += 2 * NWORK) {
-          const int e1 = __builtin_amdgcn_readfirstlane((int)bl[idx]);
-          if (idx + NWORK < nblk) {
-            const int e2 = __builtin_amdgcn_readfirstlane((int)bl[idx + NWORK]);
-            diag_update2(c, s, e1 >> 4, e1 & 15, e2 >> 4, e2 & 15, lane);
-          } else {
-            diag_update(c, s, e1 >> 4, e1 & 15, lane);
-          }
-        }
-        if (wave - 1 <= s && wave - 1 < NS) diag_store_vblock(c, s, wave - 1, lane);
       }
     }
-#ifdef PGM_DIAG_STAMPS
-    if (lane == 0 && k == 0 && s < 4) { P.partials[64 + wave * 16 + s * 2] = (double)(wb1_ - wb0_); P.partials[64 + wave * 16 + s * 2 + 1] = (double)(__builtin_amdgcn_s_memtime() - wc0_); }
-#endif
+  } else {
+    // waves 8 and 12: V_ss leaves for the two inverse images (one each)
+    const int kq = lane >> 4, n = lane & 15;
+    for (int s = 0; s < NS; ++s) {
+      v4d v;
+      if (s < nse) {
+        lds_barrier();
+        v = diag_get(c.prow + (s & 1) * NS * DB * DB + s * DB * DB, lane);
+        lds_barrier();
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (kq + 4 * r == n) ? 1.0 : 0.0;
+      }
+      diag_store_v(c, s, s, v, lane, wave == 8 ? 1 : 2);
+    }
   }
-  if (nse < NS) {                                             // inverse images of the padding: zero blocks and identities, as they stand
-    lds_barrier();
-    if (wave >= 1 && wave < DIAG_WAVES - 1)
-      for (int s = nse; s < NS; ++s)
-        if (wave - 1 <= s && wave - 1 < NS) diag_store_vblock(c, s, wave - 1, lane);
-  }
 #ifdef PGM_DIAG_STAMPS
-  STAMP();
-  if (t == 0 && (k == 0 || k == 3 || k == 25) && blockIdx.z == 0) {      // clock ticks: start, potrf(0), then per step: barrier, row solve+barrier, update(s+1,s+1), potrf(s+1)
-    printf("k=%d entry->first stamp %d: ", k, (int)(st_[0] - entry_));
-    for (int q = 0; q < sn_; ++q) printf("%d ", (int)(st_[q] - st_[0]));
-    printf("\n");
+  {   // when every wavefront of the factoring workgroup entered and left, when its stores had drained (ticks after the first entry)
+    __shared__ long long wt_[DIAG_THREADS / 64][3];
+    const long long t1_ = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t2_ = __builtin_amdgcn_s_memtime();
+    if (lane == 0) { wt_[wave][0] = entry_; wt_[wave][1] = t1_; wt_[wave][2] = t2_; }
+    __syncthreads();
+    if (t == 0 && blockIdx.z == 0) {
+      long long t0_ = wt_[0][0];
+      for (int w = 1; w < DIAG_THREADS / 64; ++w) if (wt_[w][0] < t0_) t0_ = wt_[w][0];
+      printf("waves (entry, done, drained): ");
+      for (int w = 0; w < DIAG_THREADS / 64; ++w) printf("%d:%d,%d,%d ", w, (int)(wt_[w][0] - t0_), (int)(wt_[w][1] - t0_), (int)(wt_[w][2] - t0_));
+      printf("\n");
+    }
   }
 #endif
 }
