@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
 constexpr int DB = 16;
 constexpr int PM = NB + 16;
 constexpr int DIAG_THREADS = 1024;        // 16 wavefronts: the chain wave, 14 workers, one bookkeeper
-constexpr int DIAG_WAVES = DIAG_THREADS / 64;
+
 
 __device__ __forceinline__ double readlane_d(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -315,7 +315,6 @@ struct DiagCtx {
   double* sup;      // LDS [8][256]: sub-block (i, i+1) with the steps < i applied, unsolved (the chain solves its own copy)
   double* uiS;      // uiS[k*16+m] = V_ss[m][k]
   double* udg;      // U_pp (square roots of the pivots)
-  double* pbuf;     // [4][32] mini-panel exchange buffer
   double* Akk;      // global diagonal block of the matrix
   int64_t ld;
   double* Dinv0;    // global Uinv  [p][m]
@@ -345,10 +344,26 @@ __device__ __forceinline__ v4d diag_load_block(const DiagCtx& c, int i, int j, i
 //   acc -= P^T P  ==  mfma(-row, row, acc)   (the panel row IS the A and B fragment).
 // Leaves V_ss in block s of the block row's LDS image (zero above its diagonal by construction: the identity's image
 // only ever takes multiples of earlier rows), its transpose in uiS, the pivots' square roots in udg.
-template <bool BARRIER = false>
-__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, v4d ua) {
+// Every lane gets the value its column holds in each of the wavefront's four 16-lane rows: p[q] = x of lane (q, n).  Three
+// gfx950 lane swaps per 32-bit half (v_permlane32_swap: [x0 x1 x0 x1], [x2 x3 x2 x3]; v_permlane16_swap of each with itself),
+// no LDS (the exchange through a 1-KB LDS buffer, rounds 1-2, waited behind the workers' LDS traffic; N=1000 0.308 -> 0.307 ms).
+typedef unsigned v2u_sw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rows_to_all(double x, double (&p)[4]) {
+  unsigned h[2] = {(unsigned)__double2loint(x), (unsigned)__double2hiint(x)};
+  unsigned o[4][2];
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const v2u_sw r = __builtin_amdgcn_permlane32_swap(h[w], h[w], false, false);
+    const v2u_sw lo = __builtin_amdgcn_permlane16_swap(r[0], r[0], false, false);
+    const v2u_sw hi = __builtin_amdgcn_permlane16_swap(r[1], r[1], false, false);
+    o[0][w] = lo[0]; o[1][w] = lo[1]; o[2][w] = hi[0]; o[3][w] = hi[1];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[q] = __hiloint2double((int)o[q][1], (int)o[q][0]);
+}
+
+__device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, v4d ua, bool barrier) {
   const int g = lane >> 4, n = lane & 15;
-  double* pbuf = c.pbuf;                      // [4][32]
   v4d va;                                     // identity image (C layout)
 #pragma unroll
   for (int r = 0; r < 4; ++r) va[r] = (g + 4 * r == n) ? 1.0 : 0.0;
@@ -358,13 +373,9 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, 
   // the block is finished (bookkeeping wave), which keeps ~5 instructions per pivot off the chain.
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    pbuf[g * 32 + n] = ua[m];
-    pbuf[g * 32 + 16 + n] = va[m];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double pa[4], pb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { pa[q] = pbuf[q * 32 + n]; pb[q] = pbuf[q * 32 + 16 + n]; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    rows_to_all(ua[m], pa);
+    rows_to_all(va[m], pb);
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
       const double dp = readlane_d(pa[pl], 4 * m + pl);
@@ -388,7 +399,7 @@ __device__ __forceinline__ void diag_potrf16(const DiagCtx& c, int s, int lane, 
     }
     // The second barrier of the previous step ("block row s-1 is in LDS") is nothing this wavefront waits for -- it only has to
     // be counted: met here, one mini-panel into the factorisation, the workers' row solves are over and the chain never idles at it.
-    if (BARRIER && m == 0) lds_barrier();
+    if (barrier && m == 0) lds_barrier();                     // (wave-uniform)
   }
   double* mydump = c.dump + lane;
   double* vss = c.prow + (s & 1) * (NB / DB) * DB * DB + s * DB * DB + lane;
@@ -427,8 +438,9 @@ __device__ __forceinline__ v4d diag_get(const double* src, int lane) {
 
 // finished block (s, j), j <= s, of V = U^-T: to both inverse images, straight from the registers.  A CU retires only ~10 B/clk
 // of stores: they are issued right behind the step that finished the block and drain beside the arithmetic of the next ones.
-// (Measured and not kept: the transposed image as whole 128-byte row segments, X^T made by four MFMAs against an identity --
-//  a quarter of the write requests, no faster: the bytes are what the write path counts.)
+// (The transposed image leaves as 32-byte pieces.  Measured and not kept, both no faster: whole 128-byte row segments from a
+//  transposed read of the block row's LDS image, and from X^T made by four MFMAs against an identity -- the write path counts
+//  bytes, and the workers' matrix pipes are what the early steps run out of.)
 // which: 1 = the row-major image, 2 = the transposed one, 3 = both.  (The zero triangles are cleared once, at workspace creation.)
 __device__ __forceinline__ void diag_store_v(const DiagCtx& c, int s, int j, const v4d& v, int lane, int which = 3) {
   const int kq = lane >> 4, n = lane & 15;
@@ -510,22 +522,27 @@ __device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse) 
 #endif
   STAMP();
   __builtin_amdgcn_s_setprio(3);
-  const v4d first = diag_load_block(c, 0, 0, lane);
+  v4d d = diag_load_block(c, 0, 0, lane);
   v4d x = diag_load_block(c, 0, 1, lane);                     // what step 0 needs beyond (0, 0) comes straight from memory
-  v4d d = diag_load_block(c, 1, 1, lane);
-  diag_potrf16(c, 0, lane, first);
-  STAMP();
-  for (int s = 0; s < nse; ++s) {
-    lds_barrier();
-    STAMP();
-    if (s + 1 < nse) {
-      if (s > 0) { x = diag_get(c.sup + s * DB * DB, lane); d = diag_get(c.dg + (s + 1) * DB * DB, lane); }
-      const v4d u = diag_solve(c, x, lane);                    // U(s, s+1): the chain's own copy, the bits of its owner's
+  v4d dn = diag_load_block(c, 1, 1, lane);
+  // pass s: the first barrier of step s, the chain's own solve and update, then the factorisation of sub-block s+1 (the
+  // factorisation is a long piece of straight-line code: ONE copy of it, pass -1 is sub-block 0 -- the workgroup's
+  // neighbour CU shares the instruction cache with it and runs filler tiles)
+#pragma clang loop unroll(disable)
+  for (int s = -1; s < nse; ++s) {
+    if (s >= 0) {
+      lds_barrier();
+      STAMP();
+      if (s + 1 < nse) {
+        if (s > 0) { x = diag_get(c.sup + s * DB * DB, lane); dn = diag_get(c.dg + (s + 1) * DB * DB, lane); }
+        const v4d u = diag_solve(c, x, lane);                  // U(s, s+1): the chain's own copy, the bits of its owner's
+        d = dn;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f64_16x16x4f64(-u[r], u[r], d, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f64_16x16x4f64(-u[r], u[r], d, 0, 0, 0);
+      }
+      STAMP();
     }
-    STAMP();
-    if (s + 1 < nse) diag_potrf16<true>(c, s + 1, lane, d);
+    if (s + 1 < nse) diag_potrf16(c, s + 1, lane, d, __builtin_amdgcn_readfirstlane(s) >= 0);
     else lds_barrier();
     STAMP();
   }
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   //  ~65 chained launches costs 0.4 us each, 1 % of an evaluation)
   __shared__ __attribute__((aligned(16))) double M[NB * PM];
   __shared__ double uiS[DB * DB];
-  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], dump[64], pbuf[4 * 32];
+  __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], dump[64];
   if (blockIdx.x > 0) {
     const int widx = (int)blockIdx.x - 1;
     if (widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, widx);
@@ -722,7 +739,7 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   constexpr int NS = NB / DB;
   DiagCtx c;
   c.prow = M; c.dg = M + 2 * NS * DB * DB; c.sup = c.dg + NS * DB * DB;
-  c.uiS = uiS; c.udg = udg; c.dump = dump; c.pbuf = pbuf;
+  c.uiS = uiS; c.udg = udg; c.dump = dump;
   c.Akk = P.A + b * P.sA + (int64_t)k * NB * P.ld + k * NB;
   c.ld = P.ld;
   c.Dinv0 = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
