@@ -75,7 +75,8 @@ def test_golden_fixtures(dev, golden_dir, name):
 
 
 # (1500, 2900: ragged sizes in the fused sweep, where update tiles ride in all three launch kinds of the chain)
-@pytest.mark.parametrize("n", [1, 2, 3, 127, 128, 129, 255, 257, 383, 500, 640, 900, 1100, 1300, 1500, 2900])
+# (17 ... 100: every count of 16-row sub-block steps the last diagonal block of a light curve can have, 1 ... 8)
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 40, 50, 70, 100, 127, 128, 129, 255, 257, 383, 500, 640, 900, 1100, 1300, 1500, 2900])
 def test_ragged_sizes_vs_oracle(dev, n):
     gen = torch.Generator().manual_seed(n)
     x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 500)[0]
