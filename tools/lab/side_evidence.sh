@@ -1,0 +1,15 @@
+#!/bin/bash
+# the side measurements quoted in DESIGN.md / profiles/README.md on the current library (one GPU call)
+cd $GRAFT_REPO_ROOT
+o=gpurun_out/side; mkdir -p $o
+export LD_LIBRARY_PATH=$PWD/pgmuvi_amd:$LD_LIBRARY_PATH
+( for n in 17 89 128 256 512 1000 1024 1500 2048 2560 3000 3584 4096 4608 5120 6144 8192; do tools/evalloop $n 20 1; done
+  tools/evalloop 4096 20 0
+  for n in 256 1024 4096; do tools/evalloop $n 20 1 0; done ) > $o/evalloop_sizes.txt 2>&1
+python3 bench.py --steps 20 --warmup 5 > $o/bench_line.json 2> $o/bench.err
+python3 bench.py --total-batch 512 --npoints 2048 --steps 5 --warmup 2 > $o/bench_line_total_batch512_n2048.json 2> $o/bench_total.err
+python3 tools/trainbench.py > $o/trainbench.txt 2>&1
+python3 tools/configbench.py > $o/configbench.txt 2>&1
+python3 tools/batchbench.py > $o/batchbench.txt 2>&1
+python3 tools/densebench.py > $o/densebench.txt 2>&1
+sha256sum pgmuvi_amd/libpgmuvi_hip.so > $o/lib_sha.txt
