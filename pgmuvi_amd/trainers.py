@@ -56,6 +56,13 @@ _OPTIMISERS = {
 
 def _optimiser(optim, params, lr, eps, instances=True, **kw):
     if isinstance(optim, str) and optim in _OPTIMISERS:
+        params = list(params)
+        # Parameters on the GPU: torch's fused Adam/AdamW -- the step is ONE kernel launch instead of the dozen small ones of
+        # the default (foreach) form, 0.10 ms of host time per iteration of a loop that is host-bound below N ~ 2000 (N=1024:
+        # 1517 -> 1781 it/s).  Same update rule, sums in another order: losses of a 200-step fit agree to 4e-14.
+        if optim != "SGD" and "fused" not in kw and "capturable" not in kw and params \
+                and all(p.is_cuda and torch.is_floating_point(p) for p in params):
+            kw = dict(kw, fused=True)
         return _OPTIMISERS[optim](params, lr, eps, **kw)
     if optim == "NUTS":
         raise NotImplementedError("optim='NUTS': sampling is pgmuvi_amd.mcmc's job, not train()'s")
@@ -98,8 +105,9 @@ class _Log:
     def snapshot(self, loss, slot):
         """Queues the copy of this iteration's loss and raw parameters into pinned host buffer ``slot`` behind the
         optimiser step; returns the handle ``take`` waits on."""
-        named = list(self.model.named_parameters())
-        pieces = [loss.detach().reshape(1)] + [p.detach().reshape(-1) for _, p in named]
+        if not hasattr(self, "_named"):                      # (the walk over the module tree costs 30 us; the parameters stay the same objects)
+            self._named = list(self.model.named_parameters())
+        pieces = [loss.detach().reshape(1)] + [p.detach().reshape(-1) for _, p in self._named]
         flat = torch.cat([t if t.dtype is torch.float64 else t.double() for t in pieces])
         if not hasattr(self, "_pinned"):
             self._pinned = [torch.empty(flat.numel(), dtype=torch.float64).pin_memory() for _ in range(2)]
@@ -115,7 +123,7 @@ class _Log:
         host = self._pinned[slot].numpy()
         self.loss(np.asarray(host[0], dtype=_NP_DTYPE[loss_dtype]))
         off = 1
-        for name, p in self.model.named_parameters():
+        for name, p in self._named:
             k = p.numel()
             self.results[name].append(host[off:off + k].astype(_NP_DTYPE[p.dtype]).reshape(tuple(p.shape)))
             off += k
