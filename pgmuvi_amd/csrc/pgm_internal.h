@@ -49,9 +49,11 @@ struct PgmDev {
   double* out_gnoise; // [batch][np]
   double* out_gmean;  // [batch][np]
   int* info;          // [batch]
-  unsigned long long* outp;   // [7] the caller's output pointers of THIS evaluation (mll, g_w, g_mu, g_v, g_noise, g_mean, info), left
+  unsigned long long* outp;   // [8] the caller's output pointers of THIS evaluation (mll, g_w, g_mu, g_v, g_noise, g_mean, info), left
                       //     in device memory by k_precompute: k_finalize, replayed from a graph, writes the results there
   int* info_host;     // host-mapped copy of `info` (device address) that the LAST diagonal-block launch fills in, or null
+  long long* seq_host; // host-mapped [batch]: the number of the evaluation whose status info_host[b] holds (written after it, system scope)
+  long long seq;      // number of THIS evaluation (k_precompute leaves it in outp[7]; the graph's kernels read it from there)
   double jitter, noise_scalar;
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
   double *mll, *g_w, *g_mu, *g_v, *g_noise, *g_mean;
@@ -116,7 +118,8 @@ struct pgm_ws {
   hipStream_t cap_stream;
   struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; int parts; hipGraphExec_t exec; };
   // factorisation status for the host, final as soon as the sweep is (pgm_factorisation_status)
-  hipEvent_t ev_status;  // recorded between the two parts of an evaluation
+  long long* seq_host;   // host-mapped pinned [max_batch]: evaluation number behind each info_host entry (the host polls it: no event, one graph)
+  long long* seq_host_dev;
   int* info_host;        // host-mapped pinned copy of `info`, written by the last diagonal-block launch of the sweep
   int* info_host_dev;    // its device address
   int status_batch;      // problems of the last evaluation that published a status (0: none, or inside a caller's capture)

@@ -80,6 +80,7 @@ __device__ __forceinline__ void publish_output_pointers(const PgmDev& P) {
     P.outp[0] = (unsigned long long)P.mll; P.outp[1] = (unsigned long long)P.g_w; P.outp[2] = (unsigned long long)P.g_mu;
     P.outp[3] = (unsigned long long)P.g_v; P.outp[4] = (unsigned long long)P.g_noise; P.outp[5] = (unsigned long long)P.g_mean;
     P.outp[6] = (unsigned long long)P.info_out;
+    P.outp[7] = (unsigned long long)P.seq;                   // (the evaluation's number: the last diagonal block stamps the status with it)
   }
 }
 
@@ -802,7 +803,12 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
           // first pivot that was not positive: U_pp is then NaN/inf (or 0), and so is everything after it
           if (firstbad >= 0 && *info == 0) *info = k * NB + 1 + firstbad;
           // the status is final with the last diagonal block: the host's copy (pgm_factorisation_status) is written here
-          if (k == P.nb - 1 && P.info_host) P.info_host[b] = *info;
+          // (then the evaluation's number, at system scope: a host that finds the number knows the status beside it is this evaluation's)
+          if (k == P.nb - 1 && P.info_host) {
+            P.info_host[b] = *info;
+            __threadfence_system();
+            P.seq_host[b] = (long long)P.outp[7];
+          }
         }
       }
     }
