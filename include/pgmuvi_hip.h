@@ -193,8 +193,10 @@ int pgm_lomb_scargle_f64(const double* t, const double* y, const double* dy, int
 
 /*
  * Factorisation status of the last pgm_mll_value_grad*_f64 / pgm_mll_kernel_value_grad_f64 call on `ws`, as soon as it is
- * final: waits for the event the library records after the factorisation sweep (NOT for the inverse/gradient pass that
- * follows it on the stream) and returns 0 (every problem factored) or 1, with the per-problem LAPACK-style codes in
+ * final: the last diagonal block of the sweep writes the status to host-mapped memory and stamps it with the evaluation's
+ * number; this call polls for that number (it does NOT wait for the inverse/gradient pass that follows on the stream, and
+ * the evaluation needs no event in its middle: it replays as one graph) and returns 0 (every problem factored) or 1, with
+ * the per-problem LAPACK-style codes in
  * info_host[batch] (host memory, may be NULL).  This is the host synchronisation GPyTorch's psd_safe_cholesky performs inside
  * `mll(output, y)` (pgmuvi/trainers.py:180) to decide on a jitter retry; the caller's Python work between forward and
  * backward then overlaps the rest of the evaluation.  <0: nothing to report (no evaluation yet, or it ran inside a stream
