@@ -236,3 +236,37 @@ def test_native_fit_host_side(small):
         train_native(model=m, likelihood=lik, train_x=x, train_y=y, maxiter=2)
     with pytest.raises(ValueError):
         train_native(model=m, likelihood=lik)
+
+
+def test_train_picks_the_fused_optimiser_step_only_for_gpu_parameters():
+    """``train()`` makes torch's fused Adam/AdamW when every parameter sits on the GPU (one launch per step: the loop is
+    host-bound at the sizes pgmuvi's users have); on the CPU, for SGD, and for the captured loop (capturable) it is
+    torch's default."""
+    from pgmuvi_amd import trainers
+    seen = {}
+
+    class Fake:
+        def __init__(self, cuda):
+            self.is_cuda = cuda
+
+    def spy(params, lr, eps, **kw):
+        seen["kw"] = kw
+        return "optimiser"
+
+    with mock.patch.dict(trainers._OPTIMISERS, {"AdamW": spy, "Adam": spy, "SGD": spy}), \
+            mock.patch.object(torch, "is_floating_point", lambda p: True):
+        assert trainers._optimiser("AdamW", [Fake(True), Fake(True)], 1e-3, 1e-8) == "optimiser"
+        assert seen["kw"] == {"fused": True}
+        trainers._optimiser("Adam", [Fake(True), Fake(False)], 1e-3, 1e-8)
+        assert seen["kw"] == {}
+        trainers._optimiser("AdamW", [Fake(False)], 1e-3, 1e-8)
+        assert seen["kw"] == {}
+        trainers._optimiser("SGD", [Fake(True)], 1e-3, 1e-8)
+        assert seen["kw"] == {}
+        trainers._optimiser("AdamW", [Fake(True)], 1e-3, 1e-8, capturable=True)
+        assert seen["kw"] == {"capturable": True}
+    p = torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))
+    opt = trainers._optimiser("AdamW", [p], 1e-3, 1e-8)      # (CPU parameters: torch's default form, and it steps)
+    p.grad = torch.ones(3, dtype=torch.float64)
+    opt.step()
+    assert float(p[0]) < 0.0
