@@ -1504,6 +1504,44 @@ def test_failed_factorisation_returns_nan_gradients(dev):
         assert torch.isnan(bad[k]).all(), k
 
 
+def test_host_visible_status_belongs_to_one_evaluation(dev):
+    """The factorisation status the host polls for (the last diagonal block stamps it with the evaluation's number) is that of
+    the evaluation asked about: right for a good and a failed evaluation, for single light curves of one and of several block
+    rows and for a batch with one bad member; withheld (None) once another evaluation has been enqueued on the workspace."""
+    gen = torch.Generator().manual_seed(5)
+    w, mu, v = torch.tensor([1.0], dtype=D, device=dev), torch.tensor([[0.01]], dtype=D, device=dev), torch.tensor([[1e-4]], dtype=D, device=dev)
+    for n in (60, 300, 1500):
+        x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 100)[0].reshape(n, 1).to(dev)
+        y = torch.randn(n, generator=gen, dtype=D).to(dev)
+        zero = torch.zeros(n, dtype=D, device=dev)
+        good_noise, bad_noise = torch.full((n,), 0.1, dtype=D, device=dev), torch.full((n,), -5.0, dtype=D, device=dev)
+        good = _hip.mll_value_grad(x, y, zero, good_noise, None, w, mu, v)
+        ws = good["workspace"]
+        assert good["evaluation"] == ws.last_evaluation()
+        assert ws.factorisation_failed(1, good["evaluation"]) is False
+        bad = _hip.mll_value_grad(x, y, zero, bad_noise, None, w, mu, v, workspace=ws)
+        assert bad["evaluation"] == good["evaluation"] + 1
+        assert ws.factorisation_failed(1, bad["evaluation"]) is True
+        assert ws.factorisation_failed(1, good["evaluation"]) is None          # superseded: the caller reads its own info
+        again = _hip.mll_value_grad(x, y, zero, good_noise, None, w, mu, v, workspace=ws)
+        assert ws.factorisation_failed(1, bad["evaluation"]) is None and ws.factorisation_failed(1) is False
+        torch.cuda.synchronize()
+        assert int(good["info"]) == 0 and int(bad["info"]) > 0 and int(again["info"]) == 0
+        assert float(again["mll"]) == float(good["mll"])
+    # a batch of three, the middle one not positive definite
+    n = 200
+    x = torch.sort(torch.rand(3, n, generator=gen, dtype=D) * 100, dim=1)[0].reshape(3, n, 1).to(dev)
+    y = torch.randn(3, n, generator=gen, dtype=D).to(dev)
+    noise = torch.full((3, n), 0.1, dtype=D, device=dev)
+    noise[1] = -5.0
+    out = _hip.mll_value_grad(x, y, torch.zeros(3, n, dtype=D, device=dev), noise, None, w.expand(3, 1).contiguous(),
+                              mu.expand(3, 1, 1).contiguous(), v.expand(3, 1, 1).contiguous())
+    assert out["workspace"].factorisation_failed(3, out["evaluation"]) is True
+    torch.cuda.synchronize()
+    info = out["info"].cpu()
+    assert int(info[0]) == 0 and int(info[1]) > 0 and int(info[2]) == 0
+
+
 def test_multiband_lomb_scargle_vs_oracle(dev):
     """The multiband periodogram the reference's 2-D seeding asks for (``LombScargleMultiband(...).power(f, method='fast')``,
     ``pgmuvi/multiband_ls_significance.py:51-106``): per-band powers by the HIP kernel, chi^2-weighted; config 4's 8 bands."""
