@@ -100,6 +100,7 @@ struct pgm_ws {
                          //   (no head launch on the chain from there on); >= 64: never
   double* crit;          // (inside the Dinv allocation)
   int bh, bt;            // fused sweep: update-tile budgets of the head and row-solve launches (128x128 tiles)
+  int batch_window;      // small batches in the fused sweep: rows per window (-1 auto, 0 never)
   int window;            // big single light curves: rows per window of the windowed fused sweep (0 = plain panels)
   // early inverse pass (fused sweep, one light curve): the late diagonal-block launches have fewer update tiles than
   // CUs; their spare workgroups form  R_ij = sum_p V_pi^T V_pj  over block rows p that are already final

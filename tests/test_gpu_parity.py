@@ -1295,6 +1295,37 @@ def test_lazy_plan_of_the_update_tiles_is_bit_for_bit_the_eager_one(dev, monkeyp
             assert _rel(outs["1"][f"g_{p}"].reshape(-1), outs["0"][f"g_{p}"].reshape(-1)) < 1e-11, p
 
 
+@pytest.mark.parametrize("n,batch", [(2048, 8), (2500, 5), (4000, 3)])
+def test_windows_for_small_batches_are_bit_for_bit_the_plain_fused_sweep(dev, monkeypatch, n, batch):
+    """A handful of light curves of 16 block rows and more run the fused sweep in windows of 8 block rows (the rows beyond a
+    window take its eight sources in one deep visit); PGM_BATCH_WINDOW=0 is the plain fused sweep.  Same sources in the same
+    order for every tile: value, status and residual gradients bit for bit, the spectral-mixture gradients to rounding."""
+    gen = torch.Generator().manual_seed(11 * n + batch)
+    X = torch.sort(torch.rand(batch, n, generator=gen, dtype=D) * 1500, dim=1)[0].to(dev)
+    Y = torch.randn(batch, n, generator=gen, dtype=D).to(dev)
+    Z = (0.01 + 0.05 * torch.rand(batch, n, generator=gen, dtype=D)).to(dev)
+    w = torch.tensor([0.6, 0.3, 0.2], dtype=D); mu = torch.tensor([[0.02], [0.11], [0.3]], dtype=D); v = torch.tensor([[0.003], [0.01], [0.02]], dtype=D)
+    outs = {}
+    for bw in ("-1", "0"):
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_BATCH_WINDOW", bw)
+        o = _hip.mll_value_grad(X.unsqueeze(-1), Y, torch.full_like(Y, 0.1), Z, None, w.to(dev).expand(batch, -1).contiguous(),
+                                mu.to(dev).expand(batch, -1, -1).contiguous(), v.to(dev).expand(batch, -1, -1).contiguous(), 0, 0.0, True)
+        torch.cuda.synchronize()
+        outs[bw] = {k: t.clone().cpu() for k, t in o.items() if torch.is_tensor(t)}
+    monkeypatch.delenv("PGM_BATCH_WINDOW")
+    _hip.release_workspaces()
+    assert int(outs["-1"]["info"].abs().sum()) == 0 and torch.isfinite(outs["-1"]["mll"]).all()
+    assert torch.equal(outs["-1"]["mll"], outs["0"]["mll"])
+    assert torch.equal(outs["-1"]["g_mean"], outs["0"]["g_mean"])
+    for p in ("w", "mu", "v", "noise"):
+        assert _rel(outs["-1"][f"g_{p}"].reshape(-1), outs["0"][f"g_{p}"].reshape(-1)) < 1e-11, p
+    val, gr = orc.mll_value_grad_closed_form(X[0].cpu(), Y[0].cpu(), 0.1, Z[0].cpu(), w, mu, v, 0, 0.0)
+    assert abs(float(outs["-1"]["mll"][0]) - float(val)) < MLL_TOL
+    for p in ("w", "mu", "v"):
+        assert _rel(outs["-1"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
 @pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 3970, 5120, 5130])
 def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, n):
     """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
