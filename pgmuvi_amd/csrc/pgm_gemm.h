@@ -90,21 +90,32 @@ __device__ __forceinline__ int acc_col(const WavePos& p, int tj) {
 }
 
 // n contiguous doubles (n = 1, 2, 4) at an address that is a multiple of 8 n bytes: one or two 16-byte accesses
-template <int N>
+// NT: the access carries the non-temporal hint -- a C tile that one workgroup reads once and writes once should not push the
+// operand panels that many workgroups share out of the L2 (the filler tiles of the fused sweep: -1.6 % at N=4096; the batched
+// deep updates are better off without it: 512 x N=2048 +0.7 %)
+template <int N, bool NT = false>
 __device__ __forceinline__ void load_run(const double* __restrict__ p, double (&x)[N]) {
   static_assert(N == 1 || N == 2 || N == 4, "run length");
-  if constexpr (N == 1) x[0] = p[0];
+  if constexpr (N == 1) x[0] = NT ? __builtin_nontemporal_load(p) : p[0];
   else {
 #pragma unroll
-    for (int h = 0; h < N / 2; ++h) { const v2d v = *reinterpret_cast<const v2d*>(p + 2 * h); x[2 * h] = v[0]; x[2 * h + 1] = v[1]; }
+    for (int h = 0; h < N / 2; ++h) {
+      const v2d* q = reinterpret_cast<const v2d*>(p + 2 * h);
+      const v2d v = NT ? __builtin_nontemporal_load(q) : *q;
+      x[2 * h] = v[0]; x[2 * h + 1] = v[1];
+    }
   }
 }
-template <int N>
+template <int N, bool NT = false>
 __device__ __forceinline__ void store_run(double* __restrict__ p, const double (&x)[N]) {
-  if constexpr (N == 1) p[0] = x[0];
+  if constexpr (N == 1) { if (NT) __builtin_nontemporal_store(x[0], p); else p[0] = x[0]; }
   else {
 #pragma unroll
-    for (int h = 0; h < N / 2; ++h) *reinterpret_cast<v2d*>(p + 2 * h) = v2d{x[2 * h], x[2 * h + 1]};
+    for (int h = 0; h < N / 2; ++h) {
+      v2d* q = reinterpret_cast<v2d*>(p + 2 * h);
+      const v2d v = v2d{x[2 * h], x[2 * h + 1]};
+      if (NT) __builtin_nontemporal_store(v, q); else *q = v;
+    }
   }
 }
 
@@ -256,7 +267,7 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
 }
 
 // acc = scale * C; C tile at c, pitch ldc
-template <class C>
+template <class C, bool NT = false>
 __device__ __forceinline__ void acc_load_scaled(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN], double scale) {
   const WavePos wp = wave_pos<C>();
   if constexpr (C::DIRECT) {       // a lane's TN columns of one row are contiguous: 16-byte accesses, 16 TN 8-byte runs per row
@@ -265,7 +276,7 @@ __device__ __forceinline__ void acc_load_scaled(const double* __restrict__ c, in
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double x[C::TN];
-        load_run<C::TN>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
+        load_run<C::TN, NT>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
 #pragma unroll
         for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj][r] = scale * x[tj];
       }
@@ -283,8 +294,8 @@ __device__ __forceinline__ void acc_load_scaled(const double* __restrict__ c, in
 template <class C>
 __device__ __forceinline__ void acc_load_neg(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C>(c, ldc, acc, -1.0); }
 // acc = +C, to be negated by gemm_tn(..., negate_late = true) once the first operand chunks are on their way
-template <class C>
-__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C>(c, ldc, acc, 1.0); }
+template <class C, bool NT = false>
+__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C, NT>(c, ldc, acc, 1.0); }
 template <class C>
 __device__ __forceinline__ void acc_negate(v4d (&acc)[C::TM][C::TN]) {
 #pragma unroll
@@ -300,7 +311,7 @@ __device__ __forceinline__ void acc_zero(v4d (&acc)[C::TM][C::TN]) {
     for (int tj = 0; tj < C::TN; ++tj) acc[ti][tj] = v4d{0.0, 0.0, 0.0, 0.0};
 }
 // C = sign * acc
-template <class C>
+template <class C, bool NT = false>
 __device__ __forceinline__ void acc_store(double* __restrict__ c, int64_t ldc, const v4d (&acc)[C::TM][C::TN], double sign) {
   const WavePos wp = wave_pos<C>();
   if constexpr (C::DIRECT) {
@@ -311,7 +322,7 @@ __device__ __forceinline__ void acc_store(double* __restrict__ c, int64_t ldc, c
         double x[C::TN];
 #pragma unroll
         for (int tj = 0; tj < C::TN; ++tj) x[tj] = sign * acc[ti][tj][r];
-        store_run<C::TN>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
+        store_run<C::TN, NT>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
       }
   } else {
 #pragma unroll

@@ -602,6 +602,10 @@ static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit
 // overwrites it in place; own_zero: the row has nothing pending, only that copy is made.
 // `dg` >= 0: one more tile after the planned rows', the diagonal tile of block row dg alone (one source, or two with dg_two):
 // the look-ahead of the coming row solve needs that tile up to date, the rest of its row may stay behind (run_sweep).
+#ifndef PGM_FILL_NT
+#define PGM_FILL_NT 1
+#endif
+constexpr bool FILL_NT = PGM_FILL_NT != 0;     // the fused sweep's tiles read and write their C tile with the non-temporal hint (pgm_gemm.h)
 constexpr int FILL_MAX_NB = 48;
 struct FillPlan { unsigned long long skip, two; int own, own_zero, dg, dg_two; };
 
@@ -650,7 +654,7 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
   const double* pa1 = pa0 + NB * ld;
   const double* pb1 = A + (int64_t)(pstart + 1) * NB * ld + j * NB + sj * C::BN;
   v4d acc[C::TM][C::TN];
-  if (assign) acc_zero<C>(acc); else acc_load_raw<C>(Cp, ld, acc);   // (negated inside gemm_tn: see negate_late there)
+  if (assign) acc_zero<C>(acc); else acc_load_raw<C, FILL_NT>(Cp, ld, acc);   // (negated inside gemm_tn: see negate_late there)
   if (nkb == 1) {
     gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
       pa = pa0; lda = ld; pb = pb0; ldb = ldb0;
@@ -662,7 +666,7 @@ __device__ __forceinline__ void plan_tile(const PgmDev& P, double* lds, const Fi
   } else if (!assign) {                                      // (copy only)
     acc_negate<C>(acc);
   }
-  if (!copy_only) acc_store<C>(Cp, ld, acc, -1.0);
+  if (!copy_only) acc_store<C, FILL_NT>(Cp, ld, acc, -1.0);
   if (own && syrk && tile == 0)                              // (uniform) the tile the coming row solve's look-ahead reads
     acc_store<C>(P.crit + (int64_t)b * NB * NB + (int64_t)si * C::BM * NB + sj * C::BN, NB, acc, -1.0);
 }
@@ -683,11 +687,11 @@ __device__ __forceinline__ void early_inverse_tile(const PgmDev& P, double* lds,
   const int64_t lda0 = (p > i) ? ld : NB, ldb0 = (p > j) ? ld : NB;
   v4d acc[C::TM][C::TN];
   const bool cont = (task.w & LAUUM_LOAD) != 0;
-  if (cont) acc_load_raw<C>(Rp, ld, acc); else acc_zero<C>(acc);
+  if (cont) acc_load_raw<C, FILL_NT>(Rp, ld, acc); else acc_zero<C>(acc);
   gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     pa = pa0; lda = lda0; pb = pb0; ldb = ldb0;
   }, acc, 0, cont);
-  acc_store<C>(Rp, ld, acc, -1.0);
+  acc_store<C, FILL_NT>(Rp, ld, acc, -1.0);
 }
 
 // Third filler role, diagonal block 0 only (one light curve, 1-D spectral mixture): while the first diagonal block is factored
