@@ -608,6 +608,12 @@ static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit
 constexpr bool FILL_NT = PGM_FILL_NT != 0;     // the fused sweep's tiles read and write their C tile with the non-temporal hint (pgm_gemm.h)
 constexpr int FILL_MAX_NB = 48;
 struct FillPlan { unsigned long long skip, two; int own, own_zero, dg, dg_two; };
+// Which planned tile a filler workgroup of k_diag takes (one light curve): the dispatcher deals workgroups round-robin over the
+// 8 XCDs, each with an L2 of its own, so with the plain index every XCD works on every 8th tile of every row and fetches nearly
+// all of the launch's operand tiles (~40 per source) from the memory side; the host's map gives the workgroups of one XCD a
+// block of about 4 rows x 8 columns of tiles (12 operand tiles).  Placement only: every tile is still computed once.
+// (Kernel argument = scalar loads issued with the other arguments: no dependent memory access in front of the tile.)
+struct FillMap { int on; unsigned idx[128]; };   // (two 16-bit entries per word: scalar loads are 32 bits wide)
 
 // One planned trailing-update tile (or BM x BN sub-tile of it): workgroup index widx counts the sub-tiles of
 // the planned rows >= r_from in row order.  Used by the filler workgroups of k_diag (128x128, 16 wavefronts)
@@ -721,7 +727,7 @@ __device__ __forceinline__ void build_beside_diag(const PgmDev& P, double* lds, 
   }
 }
 
-__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan, int nfill, int task_lo, int build_tiles) {
+__global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int fill_end, int fill_lo, FillPlan plan, int nfill, int task_lo, int build_tiles, FillMap map) {
   const int b = blockIdx.z;
   // (no early exit on P.info here or in k_trsm / k_update: after a failed pivot the chain kernels just
   //  carry NaNs -- no address depends on data -- and a dependent scalar load in front of every one of the
@@ -731,9 +737,10 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   __shared__ double rsv[NB], zsv[NB], alv[NB], udg[NB], dump[64];
   if (blockIdx.x > 0) {
     const int widx = (int)blockIdx.x - 1;
-    if (widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, widx);
+    const int slot = map.on ? (int)((map.idx[widx >> 1] >> (16 * (widx & 1))) & 0xffffu) : widx;   // (map: tiles and early tasks of the launch alike)
+    if (map.on ? slot < nfill : widx < nfill) plan_tile<CfgFill>(P, M, plan, fill_end, fill_lo, slot);
     else if (build_tiles > 0) build_beside_diag(P, M, widx - nfill, (int)gridDim.x - 1 - nfill, build_tiles);   // (diagonal block 0 only)
-    else early_inverse_tile<CfgFill>(P, M, P.tasks[task_lo + widx - nfill]);
+    else early_inverse_tile<CfgFill>(P, M, P.tasks[task_lo + slot - nfill]);
     return;
   }
 #ifdef PGM_DIAG_STAMPS
