@@ -84,12 +84,18 @@ def make_shard(total: int, rank: int, world: int, n: int, recipe: str = "cfg3", 
     return out if device is None else {k: v.to(device) for k, v in out.items()}
 
 
-def default_chunk(n: int, budget_bytes: float = 40e9) -> int:
+def default_chunk(n: int, budget_bytes: float = 40e9, device=None) -> int:
     """Light curves per launch set of a shard: as many as fit ``budget_bytes`` of workspace (8 N^2 bytes each and ~15 % of
     side buffers), at most 512.  More light curves per launch set means fuller launches of the latency-bound links of the
     sweep (a diagonal-block launch holds one workgroup per light curve): 64 x N=2048 per call 5020 evaluations/s, 128: 5310,
-    256: 5440, 512: 5500; N=4096: 790 / 807 / 807 (one MI355X, round 3)."""
+    256: 5440, 512: 5500; N=4096: 790 / 807 / 807 (one MI355X, round 3).  With a ``device`` the budget is also held to 60 %
+    of the memory that is free there now (a smaller or shared GPU, or another large workspace still cached)."""
     np_ = (n + 127) // 128 * 128
+    if device is not None and torch.cuda.is_available() and torch.device(device).type == "cuda":
+        try:
+            budget_bytes = min(budget_bytes, 0.6 * torch.cuda.mem_get_info(device)[0])
+        except Exception:
+            pass
     c = int(max(1, min(512, budget_bytes // (9.2 * np_ * np_))))
     return c - c % 8 if c >= 8 else c          # (multiples of 8 keep the XCD-aware placement of a batch's workgroups)
 
@@ -102,7 +108,7 @@ def sharded_batch_step(shard: Dict[str, torch.Tensor], total: int, chunk: Option
     nloc = shard["y"].shape[0]
     if nloc:
         out = evaluate_batch(shard["x"], shard["y"], shard["mean"], shard["noise"], shard["w"], shard["mu"], shard["v"],
-                             need_grad=need_grad, chunk=chunk or default_chunk(shard["y"].shape[1]), _compute=_compute)
+                             need_grad=need_grad, chunk=chunk or default_chunk(shard["y"].shape[1], device=shard["y"].device), _compute=_compute)
     else:
         out = dict(mll=torch.zeros(0, dtype=torch.float64, device=shard["y"].device),
                    info=torch.zeros(0, dtype=torch.int32, device=shard["y"].device))

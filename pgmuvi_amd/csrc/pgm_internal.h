@@ -95,7 +95,6 @@ struct pgm_ws {
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
   int build_beside;      // one light curve, 1-D spectral mixture: build the matrix below block row 0 beside diagonal block 0 (PGM_BUILD_BESIDE=0: off)
   int lazy, lazy_end;    // fused sweep: lazy plan (run_sweep), and the tile count from which it turns eager
-  int plan_dump;         // PGM_PLAN_DUMP=1: run_sweep prints its plan (the first evaluation of a problem size: graphs replay silently)
   int lookahead;         // fused sweep: first block row whose successor's diagonal tile is formed inside the row-solve launch
                          //   (no head launch on the chain from there on); >= 64: never
   double* crit;          // (inside the Dinv allocation)

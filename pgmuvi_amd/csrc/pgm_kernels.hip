@@ -302,7 +302,8 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // The arithmetic per sub-block is what it always was (4 chained MFMAs per update or solve, steps in order): results are bit
 // for bit those of rounds 1-2.
 constexpr int DIAG_WORKERS = 12, DIAG_SLOTS = 6;
-__constant__ unsigned char DIAG_OWN[DIAG_WORKERS][8] = {      // (i << 4) | j, 0xff: none
+alignas(8) __constant__ unsigned char DIAG_OWN[DIAG_WORKERS][8] = {   // (a worker reads its row as one 64-bit scalar load)
+       // (i << 4) | j, 0xff: none
   {0x02, 0x36, 0x43, 0x44, 0x55, 0x64, 0xff, 0xff}, {0x03, 0x13, 0x34, 0x51, 0x65, 0x66, 0xff, 0xff},
   {0x04, 0x16, 0x24, 0x31, 0x56, 0x62, 0xff, 0xff}, {0x20, 0x35, 0x42, 0x52, 0x74, 0xff, 0xff, 0xff},
   {0x17, 0x27, 0x60, 0x71, 0xff, 0xff, 0xff, 0xff}, {0x05, 0x15, 0x37, 0x41, 0x50, 0x75, 0xff, 0xff},
@@ -563,24 +564,9 @@ __device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse) 
 // work that neither this diagonal block nor the following row solve depends on.  A filler
 // workgroup is the same 16 wavefronts as the factoring one and multiplies one 128x128 tile at a
 // time, a 32x32 sub-tile per wavefront.
-#ifndef PGM_FILL_PF
-#define PGM_FILL_PF 2            // two chunks in flight: a 256-deep filler tile 49.6 -> 45.2 us, a 128-deep one 29.4 -> 27.3 (tools/tileprobe)
-#endif
-#ifndef PGM_FILL_KB
-#define PGM_FILL_KB 16
-#endif
-// (direct form of the multiply loop, pgm_gemm.h: fragments straight from memory, 8 k-steps in flight per wavefront)
-#ifndef PGM_DIRECT_FILL
-#define PGM_DIRECT_FILL 1
-#endif
-#ifndef PGM_FILL_PD
-#define PGM_FILL_PD 4
-#endif
-#if PGM_DIRECT_FILL
-using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PD, DIAG_THREADS, KB, true>;
-#else
-using CfgFill = TileCfg<128, 128, 32, 32, PGM_FILL_PF, DIAG_THREADS, PGM_FILL_KB>;
-#endif
+// (direct form of the multiply loop, pgm_gemm.h: fragments straight from memory, four k-steps in flight per wavefront;
+//  the staged LDS form of rounds 1-2 -- 45.2 us for a 256-deep filler tile against 41 -- is gone)
+using CfgFill = TileCfg<128, 128, 32, 32, 4, DIAG_THREADS, KB, true>;
 static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit the diagonal block image");
 
 // (A persistent variant -- one filler workgroup per CU looping over tiles with the next tile's C
@@ -602,10 +588,7 @@ static_assert(CfgFill::LDS_DOUBLES <= NB * PM, "the filler's LDS stages must fit
 // overwrites it in place; own_zero: the row has nothing pending, only that copy is made.
 // `dg` >= 0: one more tile after the planned rows', the diagonal tile of block row dg alone (one source, or two with dg_two):
 // the look-ahead of the coming row solve needs that tile up to date, the rest of its row may stay behind (run_sweep).
-#ifndef PGM_FILL_NT
-#define PGM_FILL_NT 1
-#endif
-constexpr bool FILL_NT = PGM_FILL_NT != 0;     // the fused sweep's tiles read and write their C tile with the non-temporal hint (pgm_gemm.h)
+constexpr bool FILL_NT = true;                 // the fused sweep's tiles read and write their C tile with the non-temporal hint (pgm_gemm.h)
 constexpr int FILL_MAX_NB = 48;
 struct FillPlan { unsigned long long skip, two; int own, own_zero, dg, dg_two; };
 // Which planned tile a filler workgroup of k_diag takes (one light curve): the dispatcher deals workgroups round-robin over the
@@ -867,10 +850,8 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
 using CfgTrsm = TileCfg<128, 32, 32, 32, 4>;               // (prediction right-hand sides)
 // 8 wavefronts, a 32x16 sub-tile each: the launch sits on the chain and is bound by its own latency, so the
 // multiply body is cut to 64 MFMAs per wavefront (2 us) rather than sized for operand reuse
-#ifndef PGM_TRSM_BN
-#define PGM_TRSM_BN 32
-#endif
-using CfgTrsmChain = TileCfg<128, PGM_TRSM_BN, PGM_TRSM_BN == 32 ? 32 : 16, 16, 4, 512>;
+// (16-column slabs -- twice the workgroups, half the MFMAs each -- were measured in round 2 and lost: 2.169 -> 2.178 ms)
+using CfgTrsmChain = TileCfg<128, 32, 32, 16, 4, 512>;
 using CfgLook = TileCfg<128, 32, 32, 16, 4, 512>;          // the look-ahead workgroups: two 16-column slabs each
 constexpr int TRSM_SLABS = NB / CfgTrsmChain::BN;
 using CfgHead = TileCfg<64, 64, 32, 16, 4, 512>;           // the chain's update tiles: 64x64 sub-tiles, same reasoning
@@ -1163,38 +1144,11 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 // recomputed from the per-point factors, leaving one partial sum per hyper-
 // parameter and tile (summed in fixed order by k_finalize: bitwise reproducible).
 // ---------------------------------------------------------------------------
-#ifndef PGM_BIG_PF
-#define PGM_BIG_PF 2            // two chunks in flight: 64 x N=2048 13.83 -> 13.64 ms, 8 x N=4096 12.27 -> 12.19 ms
-#endif
 // the staged form keeps the name CfgBigLds: its LDS budget is what the gradient epilogues stage their factors in
-using CfgBigLds = TileCfg<128, 128, 64, 64, PGM_BIG_PF>;
-#ifndef PGM_DIRECT_BIG
-#define PGM_DIRECT_BIG 1
-#endif
-#if PGM_DIRECT_BIG
+using CfgBigLds = TileCfg<128, 128, 64, 64, 2>;
 struct CfgBig : TileCfg<128, 128, 64, 64, 4, 256, KB, true> { static constexpr int LDS_DOUBLES = CfgBigLds::LDS_DOUBLES; };
-#else
-using CfgBig = CfgBigLds;
-#endif
-#ifndef PGM_UPD_WAVES8
-#define PGM_UPD_WAVES8 0
-#endif
-#ifndef PGM_UPD_PF
-#define PGM_UPD_PF 2
-#endif
-#if PGM_UPD_WAVES8
-using CfgUpd = TileCfg<128, 128, 64, 32, PGM_UPD_PF, 512>;      // (experiment) 8 wavefronts per 128x128 tile
-#else
-using CfgUpd = CfgBig;
-#endif
-#ifndef PGM_DIRECT_SMALL
-#define PGM_DIRECT_SMALL 1
-#endif
-#if PGM_DIRECT_SMALL
+using CfgUpd = CfgBig;                                       // (8 wavefronts per 128x128 tile: measured in round 2, -0.7 %, not kept)
 using CfgSmall = TileCfg<64, 64, 32, 32, 8, 256, KB, true>;
-#else
-using CfgSmall = TileCfg<64, 64, 32, 32, 4>;
-#endif
 using CfgSub = CfgSmall;                                     // quarter tiles of the inverse/gradient pass of short light curves
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
@@ -1289,15 +1243,6 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
     else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + no; ldb = NB; }
   }, acc, 0, cont);
 
-#ifdef PGM_LAUUM_NOEPI
-  { double sacc = 0.0;                                       // (timing experiment: multiply loop only)
-#pragma unroll
-    for (int ti = 0; ti < C::TM; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < C::TN; ++tj) sacc += acc[ti][tj][0] + acc[ti][tj][1] + acc[ti][tj][2] + acc[ti][tj][3];
-    if (sacc == 1.2345e300) P.partials[0] = 1.0; }
-  return;
-#endif
   if constexpr (SUB == 1) { if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc); }
   // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
   const int Q = P.q;

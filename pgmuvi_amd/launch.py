@@ -9,12 +9,15 @@ children of the same command line -- one per rank, with ``RANK`` / ``LOCAL_RANK`
 has initialised the GPU is ever replaced by another program (that takes the whole
 machine down on this pool): children are started with ``subprocess.Popen``.
 
-Nothing here imports torch; the caller passes the number of visible devices (counted with
-``torch.cuda.device_count()``, which does not initialise HIP on this image).
+Nothing here imports torch; the caller passes the number of visible devices.  (``bench.py`` counts them with
+``torch.cuda.device_count()``, which on ROCm may open the HIP runtime in the parent; that was only verified to be harmless
+here -- the parent never launches GPU work and only ever starts fresh children, and the one-rank spawn path is green on
+the GPU box -- not to leave the runtime untouched.)
 """
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -63,12 +66,35 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
     if visible_devices is not None and visible_devices < world:
         print(f"launch: --gpus {world} needs {world} visible GPUs, this host shows {visible_devices}", file=err)
         return 2
-    port = free_port()
+    port = free_port()                                         # (closed before rank 0 binds it: a small window another process could take it in)
     procs: List[subprocess.Popen] = []
     try:
         child_err = err.fileno()                               # (a real descriptor: the children write to it directly)
     except (AttributeError, OSError, ValueError):
         child_err = None                                       # inherit this process's stderr
+
+    def stop_children(sig):                                    # exactly the processes started below, by handle
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+
+    # a driver that ends the parent on a time-out must not leave N processes holding GPUs: the parent passes SIGTERM / SIGINT
+    # on to its children and leaves through the ``finally`` below (only in the main thread: signal handlers live there)
+    previous = {}
+
+    def on_signal(signum, frame):
+        stop_children(signal.SIGTERM)
+        raise KeyboardInterrupt(f"launch: signal {signum}")
+
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            try:
+                previous[sg] = signal.signal(sg, on_signal)
+            except (OSError, ValueError):
+                pass
     try:
         for r in range(world):
             procs.append(subprocess.Popen(list(argv), env=rank_environment(r, world, port),
@@ -82,7 +108,7 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
                 out.flush()
         reader = threading.Thread(target=relay, daemon=True)
         reader.start()
-        status, failed_at = 0, None
+        status, failed_at, terminated_at = 0, None, None
         pending = set(range(world))
         while pending:
             for r in sorted(pending):
@@ -93,14 +119,19 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
                 if rc != 0 and status == 0:
                     status, failed_at = rc, time.monotonic()
                     print(f"launch: rank {r} exited with status {rc}", file=err)
-            if pending and failed_at is not None and time.monotonic() - failed_at > grace_s:
-                for r in pending:                                # (exactly the processes started above, by handle)
-                    procs[r].terminate()
-                failed_at = time.monotonic() + 1e9
+            now = time.monotonic()
+            if pending and failed_at is not None and terminated_at is None and now - failed_at > grace_s:
+                stop_children(signal.SIGTERM)
+                terminated_at = now
+            elif pending and terminated_at is not None and now - terminated_at > grace_s:
+                stop_children(signal.SIGKILL)                   # (a rank that ignores or blocks SIGTERM)
+                terminated_at = now
             if pending:
                 time.sleep(0.05)
         reader.join(timeout=10)
         return status if status >= 0 else 128 - status             # (killed by a signal: the shell's convention)
+    except KeyboardInterrupt:
+        return 130
     finally:
         for p in procs:
             if p.poll() is None:
@@ -109,4 +140,9 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
             try:
                 p.wait(timeout=10)
             except Exception:
+                pass
+        for sg, h in previous.items():
+            try:
+                signal.signal(sg, h)
+            except (OSError, ValueError):
                 pass

@@ -8,6 +8,7 @@ gradients.  Constraint transforms and the mean module stay in torch autograd (A2
 """
 from __future__ import annotations
 
+import threading
 import warnings
 
 import torch
@@ -28,16 +29,38 @@ def _failed(out) -> bool:
     return bool((info != 0).any()) if status is None else status
 
 
-_deferred = []          # evaluations whose factorisation status nobody has asked for yet (settings.defer_cholesky_check)
+class _Deferred(threading.local):
+    """Evaluations whose factorisation status nobody has asked for yet (``settings.defer_cholesky_check``): per thread -- a
+    second thread's training loop must not collect this one's -- and bounded, so that a caller who switches the flag on and
+    never asks does not pin every evaluation's workspace and gradient buffers (the oldest entries are simply forgotten)."""
+    LIMIT = 8
+
+    def __init__(self):
+        self.items = []
+
+
+_deferred = _Deferred()
+
+
+def _defer(out):
+    _deferred.items.append(out)
+    if len(_deferred.items) > _Deferred.LIMIT:
+        del _deferred.items[: len(_deferred.items) - _Deferred.LIMIT]
+
+
+def drop_deferred():
+    """Forget the pending evaluations (a loop's ``finally``: an exception between the evaluation and the status query)."""
+    _deferred.items.clear()
 
 
 def take_deferred_failure() -> bool:
-    """Did any evaluation run under ``settings.defer_cholesky_check`` since the last call fail to factor?  Waits for the
-    factorisation sweep of those evaluations only (by the time a training loop asks -- after ``loss.backward()`` -- it is
-    usually over)."""
+    """Did any evaluation run under ``settings.defer_cholesky_check`` since the last call (on this thread) fail to factor?
+    Waits for the factorisation sweep of those evaluations only (by the time a training loop asks -- after
+    ``loss.backward()`` -- it is usually over)."""
     failed = False
-    while _deferred:
-        failed = _failed(_deferred.pop()) or failed
+    items, _deferred.items = _deferred.items, []
+    for out in items:
+        failed = _failed(out) or failed
     return failed
 
 
@@ -48,7 +71,7 @@ def _evaluate(x, y, mean, noise_vec, noise_scalar, w, mu, v, dim_order, need_gra
     if settings.check_cholesky_info.off():
         return out, 0.0
     if settings.defer_cholesky_check.on():
-        _deferred.append(out)
+        _defer(out)
         return out, 0.0
     if not _failed(out):
         return out, 0.0
@@ -161,7 +184,7 @@ def _evaluate_kernel(x, y, mean, noise_vec, noise_scalar, program, theta, need_g
     if settings.check_cholesky_info.off():
         return out, 0.0
     if settings.defer_cholesky_check.on():
-        _deferred.append(out)
+        _defer(out)
         return out, 0.0
     if not _failed(out):
         return out, 0.0

@@ -184,10 +184,18 @@ def train(lightcurve=None, model=None, likelihood=None, train_x=None, train_y=No
         # GPU through the host's backward).  A failed factorisation -- rare -- repeats the iteration's forward and backward
         # in the ordinary mode, where GPyTorch's jitter-retry policy (warning, NotPSDError) applies: the step is taken on
         # the same value and gradients as without the deferral.
-        with settings.defer_cholesky_check(True):
-            loss = -objective(model(train_x), train_y)
-            loss.backward()
-        if mll_function.take_deferred_failure():
+        try:
+            with settings.defer_cholesky_check(True):
+                loss = -objective(model(train_x), train_y)
+                # (anomaly detection wants to see the first NaN where it arises: there the status is read before backward,
+                #  as in the ordinary mode, and a failed evaluation is not back-propagated at all)
+                failed = mll_function.take_deferred_failure() if torch.is_anomaly_enabled() else None
+                if not failed:
+                    loss.backward()
+        except BaseException:
+            mll_function.drop_deferred()                     # (nothing of this iteration stays pinned behind the exception)
+            raise
+        if failed or (failed is None and mll_function.take_deferred_failure()):
             optimizer.zero_grad()
             loss = -objective(model(train_x), train_y)
             loss.backward()
