@@ -111,6 +111,34 @@ int pgm_mll_value_grad_batched_f64(pgm_ws* ws, int batch,
                                    double* g_noise, double* g_mean, int* info, void* stream);
 
 /*
+ * The same for `batch` light curves of DIFFERENT lengths -- what a real many-light-curve batch is: every
+ * pgmuvi `Lightcurve` carries its own N and is subsampled to its own length (pgmuvi/lightcurve.py:1724-1733,
+ * 2150-2181), and each is the unit of work of pgmuvi/trainers.py:179-181 ("for ragged N
+ * sort by N^3").
+ *   n_host (HOST array, batch entries): points of light curve b, 1 <= n_b <= stride_n, n_b <= the workspace's max_n;
+ *   per-point arrays are padded to a common pitch: x is batch x stride_n x d, y / mean / noise / g_noise / g_mean are
+ *   batch x stride_n (entries beyond n_b are neither read nor written); w, mu, v, mll, g_w, g_mu, g_v, info as in
+ *   the batched call.
+ * The light curves are taken in order of their 128-row block count and advance in launch sets of at most the
+ * workspace's max_batch members: a set shares its block-row count, the members that are shorter end in identity
+ * padding (which changes no bit of their value: batched == single, bit for bit); lengths join the next longer set
+ * where that is cheaper than a launch set of their own (pgm_ragged_plan shows the sets).  The length table is
+ * uploaded when it differs from the previous call's (one host synchronisation; none for a fit loop over the same
+ * light curves).  Not inside a stream capture (-24).
+ */
+int pgm_mll_value_grad_ragged_f64(pgm_ws* ws, int batch,
+                                  const double* x, const double* y, const double* mean,
+                                  const double* noise, const double* noise_scalar,
+                                  const int64_t* n_host, int64_t stride_n, int d,
+                                  const double* w, const double* mu, const double* v, int q,
+                                  int dim_order, double jitter, int need_grad,
+                                  double* mll, double* g_w, double* g_mu, double* g_v,
+                                  double* g_noise, double* g_mean, int* info, void* stream);
+/* Host only (no GPU): the launch sets of such a call.  set_of_host[b] (batch entries, may be NULL) = the set light curve b
+ * runs in, nb_of_set_host[s] (up to batch entries, may be NULL) = the set's block rows; returns the number of sets. */
+int pgm_ragged_plan(const int64_t* n_host, int batch, int max_batch, int* set_of_host, int* nb_of_set_host);
+
+/*
  * Posterior prediction at n_test inputs from the factor left in the workspace by
  * the last pgm_mll_value_grad_f64 call with need_grad != 0 (alpha and
  * L^-1 are kept):  mean_out = mean_test + K*^T alpha,

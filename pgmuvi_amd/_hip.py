@@ -37,6 +37,11 @@ SYMBOLS = {
                                                c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double,
                                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
+    "pgm_mll_value_grad_ragged_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double,
+                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
+    "pgm_ragged_plan": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pgm_predict_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "pgm_profile_enable": (c_int, [c_void_p, c_int]),
     "pgm_profile_phases": (c_int, []),
@@ -368,6 +373,69 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     out["_buf"], out["_offs"] = buf, offs                    # (one contiguous buffer: a caller can scale every gradient with one multiply)
     out["workspace"] = ws
     out["evaluation"] = ws.last_evaluation()
+    return out
+
+
+def ragged_plan(lengths, max_batch: int):
+    """The launch sets ``pgm_mll_value_grad_ragged_f64`` forms for these light-curve lengths (host only, no GPU):
+    (set index of every light curve, block rows of every set)."""
+    import numpy as np
+    n = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+    set_of = np.zeros(len(n), dtype=np.int32)
+    nb_of = np.zeros(len(n), dtype=np.int32)
+    k = load().pgm_ragged_plan(n.ctypes.data_as(c_void_p), len(n), int(max_batch), set_of.ctypes.data_as(c_void_p),
+                               nb_of.ctypes.data_as(c_void_p))
+    if k < 0:
+        raise RuntimeError(f"pgm_ragged_plan failed with status {k}")
+    return set_of.tolist(), nb_of[:k].tolist()
+
+
+def mll_value_grad_ragged(x, y, mean, noise, noise_scalar, lengths, w, mu, v, dim_order=0, jitter=0.0, need_grad=True,
+                          workspace: Optional[Workspace] = None, max_batch: Optional[int] = None):
+    """MLL (+ gradients) of B light curves of different lengths through pgm_mll_value_grad_ragged_f64.
+
+    Padded layout: x (B,S,d) y (B,S) mean (B,S) noise (B,S)|None, ``lengths`` the B point counts (host integers, each <= S);
+    noise_scalar (B,)|None; w (B,q) mu (B,q,d) v (B,q,d).  Entries beyond a light curve's length are ignored; g_noise /
+    g_mean come back (B,S) with zeros there.  ``max_batch``: light curves per launch set (workspace memory)."""
+    import numpy as np
+    require_gpu(x, "mll_value_grad_ragged")
+    dev = x.device
+    B, S = y.shape
+    n = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+    if n.shape != (B,) or n.min() < 1 or n.max() > S:
+        raise ValueError(f"mll_value_grad_ragged: {B} lengths in [1, {S}] expected")
+    xd = _dev64(x, dev)
+    d = xd.numel() // (B * S)
+    q = w.shape[-1]
+    yd = _dev64(y, dev)
+    md = _dev64(mean if mean.shape == y.shape else mean.expand(y.shape), dev)
+    nz = None if noise is None else _dev64(noise if noise.shape == y.shape else noise.expand(y.shape), dev)
+    ns = None if noise_scalar is None else _dev64(torch.as_tensor(noise_scalar, device=dev).expand(B).reshape(B), dev)
+    wd, mud, vd = _dev64(w, dev), _dev64(mu, dev), _dev64(v, dev)
+    if xd.numel() != B * S * d or wd.numel() != B * q or mud.numel() != B * q * d or vd.numel() != B * q * d:
+        raise ValueError(f"mll_value_grad_ragged: inconsistent shapes x {tuple(x.shape)} y {tuple(y.shape)} w {tuple(w.shape)}")
+    ws = workspace or get_workspace(dev, int(n.max()), q, d, min(B, max_batch or B))
+    qd = q * d
+    sizes = (B, B * q, B * qd, B * qd, B * S, B * S) if need_grad else (B,)
+    buf = torch.zeros(sum(sizes), dtype=torch.float64, device=dev)
+    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + sz)
+    base = buf.data_ptr()
+    gp = [base + 8 * offs[i] for i in range(6)] if need_grad else [base, None, None, None, None, None]
+    with torch.cuda.device(dev):
+        rc = load().pgm_mll_value_grad_ragged_f64(
+            ws.handle, B, xd.data_ptr(), yd.data_ptr(), md.data_ptr(), None if nz is None else nz.data_ptr(),
+            None if ns is None else ns.data_ptr(), n.ctypes.data_as(c_void_p), S, d, wd.data_ptr(), mud.data_ptr(), vd.data_ptr(), q,
+            int(dim_order), float(jitter), 1 if need_grad else 0, gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], info.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream)
+    _check(rc, "pgm_mll_value_grad_ragged_f64")
+    out = _Outputs(buf, offs, {"mll": (0, (B,)), "g_w": (1, (B, q)), "g_mu": (2, (B, q, d)), "g_v": (3, (B, q, d)),
+                               "g_noise": (4, (B, S)), "g_mean": (5, (B, S))} if need_grad else {"mll": (0, (B,))})
+    out["info"] = info
+    out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
+    out["workspace"] = ws
     return out
 
 

@@ -8,7 +8,7 @@ gradients) over RCCL/xGMI closes the step.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -26,7 +26,8 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def balanced_assignment(costs: Sequence[float], world: int):
-    """Ragged N: sort by cost (N^3) and deal to the currently lightest rank (LPT)."""
+    """Ragged N: sort by cost (N^3) and deal to the currently lightest rank (longest processing time first); ties go to the
+    lower rank / lower index, so every rank computes the same table.  Used by :func:`make_ragged_shard`."""
     order = sorted(range(len(costs)), key=lambda i: -costs[i])
     load = [0.0] * world
     owner = [0] * len(costs)
@@ -56,6 +57,122 @@ def evaluate_batch(x, y, mean, noise, w, mu, v, noise_scalar=None, dim_order=0, 
         outs.append(o)
     keys = ["mll", "info"] + (["g_w", "g_mu", "g_v", "g_noise", "g_mean"] if need_grad else [])
     return {k: torch.cat([o[k] for o in outs]) for k in keys}
+
+
+def pad_curves(curves: Sequence[Dict[str, torch.Tensor]], device=None) -> Tuple[Dict[str, torch.Tensor], List[int]]:
+    """Light curves of different lengths -> the padded arrays of the ragged entry point.  Each curve is a dictionary with
+    x (N_i, d) | (N_i,), y (N_i,), noise (N_i,), mean () | (N_i,), w (Q,), mu (Q, d) | (Q,), v (Q, d) | (Q,).  Returns
+    ({x (B,S,d), y, mean, noise (B,S), w (B,Q), mu, v (B,Q,d)}, lengths) with S = the longest light curve; the padding
+    entries are zero (never read by the library)."""
+    B = len(curves)
+    lengths = [int(c["y"].shape[0]) for c in curves]
+    S = max(lengths)
+    d = 1 if curves[0]["x"].dim() == 1 else int(curves[0]["x"].shape[1])
+    q = int(curves[0]["w"].numel())
+    D = torch.float64
+    out = dict(x=torch.zeros(B, S, d, dtype=D), y=torch.zeros(B, S, dtype=D), mean=torch.zeros(B, S, dtype=D),
+               noise=torch.zeros(B, S, dtype=D), w=torch.zeros(B, q, dtype=D), mu=torch.zeros(B, q, d, dtype=D),
+               v=torch.zeros(B, q, d, dtype=D))
+    for b, c in enumerate(curves):
+        n = lengths[b]
+        out["x"][b, :n] = c["x"].to(D).reshape(n, d).cpu()
+        out["y"][b, :n] = c["y"].to(D).cpu()
+        out["noise"][b, :n] = c["noise"].to(D).cpu()
+        out["mean"][b, :n] = c["mean"].to(D).cpu().expand(n)
+        out["w"][b] = c["w"].to(D).reshape(q).cpu()
+        out["mu"][b] = c["mu"].to(D).reshape(q, d).cpu()
+        out["v"][b] = c["v"].to(D).reshape(q, d).cpu()
+    if device is not None:
+        out = {k: t.to(device) for k, t in out.items()}
+    return out, lengths
+
+
+def evaluate_ragged(curves=None, padded: Optional[Dict[str, torch.Tensor]] = None, lengths: Optional[Sequence[int]] = None,
+                    dim_order=0, need_grad=True, chunk: Optional[int] = None, device=None, _compute=None) -> Dict[str, object]:
+    """MLL (+ gradients) of light curves of DIFFERENT lengths on the local device -- what a real many-light-curve batch is
+    (every pgmuvi ``Lightcurve`` has its own N, ``/root/reference/pgmuvi/lightcurve.py:1724-1733, 2150-2181``).
+
+    Either ``curves`` (a list of per-curve dictionaries, see :func:`pad_curves`) or the ``padded`` arrays with ``lengths``.
+    The library sorts the light curves by their block-row count -- i.e. by N^3, SURVEY.md section 8e -- and runs them in
+    launch sets that share a chain length (``pgm_mll_value_grad_ragged_f64``); ``chunk`` bounds the light curves per launch
+    set (workspace memory, default :func:`default_chunk` of the longest).  Returns mll (B,), info (B,), g_w (B,Q), g_mu,
+    g_v (B,Q,d) and g_noise / g_mean as lists of B vectors of each light curve's own length."""
+    if padded is None:
+        padded, lengths = pad_curves(curves, device=device)
+    lengths = [int(n) for n in lengths]
+    compute = _compute or _hip.mll_value_grad_ragged
+    B = len(lengths)
+    chunk = chunk or default_chunk(max(lengths), device=padded["y"].device)
+    o = compute(padded["x"], padded["y"], padded["mean"], padded.get("noise"), padded.get("noise_scalar"), lengths,
+                padded["w"], padded["mu"], padded["v"], dim_order, 0.0, need_grad, max_batch=max(1, min(chunk, B)))
+    out = {"mll": o["mll"], "info": o["info"], "lengths": lengths}
+    if need_grad:
+        out.update(g_w=o["g_w"], g_mu=o["g_mu"], g_v=o["g_v"])
+        out["g_noise"] = [o["g_noise"][b, :n] for b, n in enumerate(lengths)]
+        out["g_mean"] = [o["g_mean"][b, :n] for b, n in enumerate(lengths)]
+    return out
+
+
+def ragged_lengths(total: int, n_lo: int, n_hi: int, seed: int = 4) -> List[int]:
+    """Lengths of a synthetic ragged batch: N_i ~ U{n_lo .. n_hi} from ``default_rng(seed)`` (a function of i only)."""
+    import numpy as np
+    return [int(v) for v in np.random.default_rng(seed).integers(n_lo, n_hi + 1, size=total)]
+
+
+def make_ragged_shard(total: int, rank: int, world: int, n_lo: int, n_hi: int, seed: int = 4, device=None) -> Dict[str, object]:
+    """This rank's light curves of a synthetic ragged batch: light curve i (the cfg-3 recipe at its own length N_i) depends on
+    (i, N_i) only; the owner of every light curve comes from :func:`balanced_assignment` on the costs N_i^3 (SURVEY.md
+    section 8e: "for ragged N sort by N^3 and deal round-robin") -- the same table on every rank."""
+    from . import synthetic as syn
+    lengths = ragged_lengths(total, n_lo, n_hi, seed)
+    owner = balanced_assignment([float(n) ** 3 for n in lengths], world)
+    mine = [i for i in range(total) if owner[i] == rank]
+    curves = []
+    for i in mine:
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=lengths[i])
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        curves.append(dict(x=t.double(), y=y.double(), noise=e.double() ** 2, mean=h["mean"], w=h["w"], mu=h["mu"], v=h["v"]))
+    padded, lens = pad_curves(curves, device=device) if curves else ({}, [])
+    return dict(index=mine, owner=owner, lengths=lengths, curves=curves, padded=padded, local_lengths=lens)
+
+
+def sharded_ragged_step(shard: Dict[str, object], need_grad=True, chunk: Optional[int] = None, group=None, device=None,
+                        _compute=None) -> Tuple[Dict[str, object], torch.Tensor]:
+    """One evaluation of a ragged batch whose light curves are dealt to the ranks by cost (see :func:`make_ragged_shard`):
+    each rank evaluates its own light curves, then ONE all_gather of the log-likelihoods.  Returns (local outputs, the
+    log-likelihoods of the whole batch in the batch's own order, identical on every rank)."""
+    total = len(shard["owner"])
+    if shard["index"]:
+        out = evaluate_ragged(padded=shard["padded"], lengths=shard["local_lengths"], need_grad=need_grad, chunk=chunk,
+                              _compute=_compute)
+        local = out["mll"]
+    else:
+        dev = device if device is not None else "cpu"
+        out = dict(mll=torch.zeros(0, dtype=torch.float64, device=dev), info=torch.zeros(0, dtype=torch.int32, device=dev))
+        local = out["mll"]
+    if group is False:
+        return out, local
+    return out, gather_by_owner(local, shard["owner"], group=group)
+
+
+def gather_by_owner(local: torch.Tensor, owner: Sequence[int], group=None) -> torch.Tensor:
+    """all_gather of per-curve values when light curve i lives on rank owner[i] (each rank holds its own in ascending i):
+    one collective of equal-sized padded buffers, then every value goes to its place in the batch's order."""
+    total = len(owner)
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    index = [[i for i in range(total) if owner[i] == r] for r in range(world)]
+    width = max(1, max(len(ix) for ix in index))
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    buf = torch.empty((world * width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r, ix in enumerate(index):
+        if ix:
+            out[torch.as_tensor(ix, device=local.device)] = buf[r * width: r * width + len(ix)]
+    return out
 
 
 def make_shard(total: int, rank: int, world: int, n: int, recipe: str = "cfg3", device=None) -> Dict[str, torch.Tensor]:

@@ -49,7 +49,13 @@ struct PgmDev {
   double* out_gnoise; // [batch][np]
   double* out_gmean;  // [batch][np]
   int* info;          // [batch]
-  unsigned long long* outp;   // [8] the caller's output pointers of THIS evaluation (mll, g_w, g_mu, g_v, g_noise, g_mean, info), left
+  // ragged batches (pgm_mll_value_grad_ragged_f64): light curves of different lengths in one launch set.  All of them share
+  // np / nb (the set's block-row count); the ones that are shorter end in identity padding, whole block rows of it if need be.
+  const int* nvec;    // [batch] points of light curve b, or null: every light curve has P.n
+  const int* cmap;    // [batch] the caller's index of workspace slot b (the sets are formed from a sorted order), or null: b
+  int64_t cstride;    // points per light curve slot in the caller's arrays (= n unless ragged); k_finalize, replayed from a graph,
+                      //   reads it from outp[8]
+  unsigned long long* outp;   // [16] the caller's output pointers of THIS evaluation (mll, g_w, g_mu, g_v, g_noise, g_mean, info), left
                       //     in device memory by k_precompute: k_finalize, replayed from a graph, writes the results there
   int* info_host;     // host-mapped copy of `info` (device address) that the LAST diagonal-block launch fills in, or null
   long long* seq_host; // host-mapped [batch]: the number of the evaluation whose status info_host[b] holds (written after it, system scope)
@@ -77,6 +83,9 @@ struct pgm_ws {
   double *A, *Dinv, *pre, *r, *z, *alpha, *logdet, *partials, *hyp, *dpart, *diagadd, *out_small, *out_gnoise, *out_gmean;
   unsigned long long* outp;
   int* info;
+  int* ragged_tab;       // device [2 * ragged_cap]: nvec | cmap of the last ragged call, in its sorted order (grown on demand)
+  int ragged_cap;
+  std::vector<int> ragged_host;   // what ragged_tab holds (a repeated call with the same lengths uploads nothing)
   int4* items;           // device copy of the work-item table
   std::vector<int4> items_host;
   int items_nb, items_batch, items_count, items_cap, items_kc;
@@ -116,7 +125,7 @@ struct pgm_ws {
   // hipGraph replay of the launch sequence behind k_precompute
   bool use_graph;
   hipStream_t cap_stream;
-  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; int parts; hipGraphExec_t exec; };
+  struct GraphEntry { int n, d, q, dim_order, need_grad, batch, panel; int early; uint64_t prog_hash; int parts; const int* nvec; hipGraphExec_t exec; };
   // factorisation status for the host, final as soon as the sweep is (pgm_factorisation_status)
   long long* seq_host;   // host-mapped pinned [max_batch]: evaluation number behind each info_host entry (the host polls it: no event, one graph)
   long long* seq_host_dev;

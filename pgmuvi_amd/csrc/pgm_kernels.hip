@@ -75,12 +75,17 @@ __device__ __forceinline__ void xcd_batch_remap(int& x, int& b) {
 // trigonometry, only the N*Q*d sincospi here.
 // The caller's output pointers of this evaluation go to device memory: k_precompute is launched with them as arguments,
 // k_finalize is replayed from a graph captured once per problem shape and reads them from there.
+// points of light curve b / its index in the caller's arrays (ragged batches: pgm_internal.h)
+__device__ __forceinline__ int pts(const PgmDev& P, int b) { return P.nvec ? P.nvec[b] : P.n; }
+__device__ __forceinline__ int caller_slot(const PgmDev& P, int b) { return P.cmap ? P.cmap[b] : b; }
+
 __device__ __forceinline__ void publish_output_pointers(const PgmDev& P) {
   if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 64 && P.outp) {
     P.outp[0] = (unsigned long long)P.mll; P.outp[1] = (unsigned long long)P.g_w; P.outp[2] = (unsigned long long)P.g_mu;
     P.outp[3] = (unsigned long long)P.g_v; P.outp[4] = (unsigned long long)P.g_noise; P.outp[5] = (unsigned long long)P.g_mean;
     P.outp[6] = (unsigned long long)P.info_out;
     P.outp[7] = (unsigned long long)P.seq;                   // (the evaluation's number: the last diagonal block stamps the status with it)
+    P.outp[8] = (unsigned long long)P.cstride;
   }
 }
 
@@ -88,25 +93,27 @@ __device__ __forceinline__ void publish_output_pointers(const PgmDev& P) {
 __global__ __launch_bounds__(256) void k_precompute(PgmDev P) {
   const int b = blockIdx.z;
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const int cb = caller_slot(P, b), n = pts(P, b);           // (the caller's arrays: slot cb, P.cstride points apart)
   if (blockIdx.x == 0 && threadIdx.x == 0) P.info[b] = 0;
   publish_output_pointers(P);
   if (blockIdx.x == 0 && threadIdx.x < P.q + 2 * P.qd) {
     const int s = threadIdx.x;
     double val;
-    if (s < P.q) val = P.w[(int64_t)b * P.q + s];
-    else if (s < P.q + P.qd) val = P.mu[(int64_t)b * P.qd + (s - P.q)];
-    else val = P.v[(int64_t)b * P.qd + (s - P.q - P.qd)];
+    if (s < P.q) val = P.w[(int64_t)cb * P.q + s];
+    else if (s < P.q + P.qd) val = P.mu[(int64_t)cb * P.qd + (s - P.q)];
+    else val = P.v[(int64_t)cb * P.qd + (s - P.q - P.qd)];
     P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + s] = val;
   }
   if (i >= P.np) return;
   double* pre = P.pre + b * P.sPre;
-  const bool valid = i < P.n;
+  const bool valid = i < n;
+  const int64_t ci = (int64_t)cb * P.cstride + i;
   for (int dd = 0; dd < P.d; ++dd) {
-    const double xi = valid ? P.x[((int64_t)b * P.n + i) * P.d + dd] : 0.0;
+    const double xi = valid ? P.x[ci * P.d + dd] : 0.0;
     pre[(int64_t)(3 * P.qd + dd) * P.np + i] = xi;
     for (int q = 0; q < P.q; ++q) {
       const int qd = q * P.d + dd;
-      const double mu = P.mu[(int64_t)b * P.qd + qd], v = P.v[(int64_t)b * P.qd + qd];
+      const double mu = P.mu[(int64_t)cb * P.qd + qd], v = P.v[(int64_t)cb * P.qd + qd];
       double s, c;
       sincospi(2.0 * (xi * mu), &s, &c);
       pre[(int64_t)(qd * 3 + 0) * P.np + i] = c;
@@ -115,9 +122,9 @@ __global__ __launch_bounds__(256) void k_precompute(PgmDev P) {
     }
   }
   const int64_t vi = (int64_t)b * P.sVec + i;
-  P.r[vi] = valid ? (P.y[(int64_t)b * P.n + i] - P.mean[(int64_t)b * P.n + i]) : 0.0;
+  P.r[vi] = valid ? (P.y[ci] - P.mean[ci]) : 0.0;
   // everything added to the diagonal: fixed noise + scalar noise + jitter (identity on the padding)
-  P.diagadd[vi] = valid ? ((P.noise ? P.noise[(int64_t)b * P.n + i] : 0.0) + P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[b] : 0.0) + P.jitter) : 0.0;
+  P.diagadd[vi] = valid ? ((P.noise ? P.noise[ci] : 0.0) + P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0) + P.jitter) : 0.0;
 }
 
 // stage the per-point factor slices of block row `ib` and block column `jb` in LDS
@@ -171,6 +178,7 @@ template <int SPLIT>
 __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* rowd, const double* cold, const double* wl,
                                               int b, int ib, int jb, int part, int tid) {
   double* A = P.A + b * P.sA;
+  const int n = pts(P, b);
   const int c2 = (tid & 63) * 2, rg = tid >> 6;
     // 1-D: mixtures outermost, the thread's two column factors in registers, its 32 x 2 entries accumulated in
     // registers: three LDS reads (the row's factors, broadcast) per two entries and mixture instead of nine
@@ -202,7 +210,7 @@ __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* row
       for (int u = 0; u < 2; ++u) {
         const int gj = jb * NB + c2 + u;
         double val = acc[rr][u];
-        if (gi < P.n && gj < P.n) { if (gi == gj) val += P.diagadd[b * P.sVec + gi]; }
+        if (gi < n && gj < n) { if (gi == gj) val += P.diagadd[b * P.sVec + gi]; }
         else val = (gi == gj) ? 1.0 : 0.0;
         out[u] = val;
       }
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
     build_part_1d<SPLIT>(P, rowd, cold, wl, b, ib, jb, part, threadIdx.x);
     return;
   }
+  const int n = pts(P, b);
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int m = rg + 4 * rr;
     const int gi = ib * NB + m;
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
     for (int u = 0; u < 2; ++u) {
       const int nloc = c2 + u, gj = jb * NB + nloc;
       double val;
-      if (gi < P.n && gj < P.n) {
+      if (gi < n && gj < n) {
         val = sm_pair<D, ORDER>(rowd, cold, wl, P.q, m, nloc);
         if (gi == gj) val += P.diagadd[b * P.sVec + gi];
       } else {
@@ -545,7 +554,7 @@ __device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse) 
       STAMP();
     }
     if (s + 1 < nse) diag_potrf16(c, s + 1, lane, d, __builtin_amdgcn_readfirstlane(s) >= 0);
-    else lds_barrier();
+    else if (s >= 0) lds_barrier();                            // (nse = 0, a block of padding: no step, no barrier)
     STAMP();
   }
 #ifdef PGM_DIAG_STAMPS
@@ -741,7 +750,10 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
   c.Dinv1 = c.Dinv0 + NB * NB;
   // The last block of a light curve whose length is no multiple of 128 ends in identity padding, decoupled from the data:
   // the sub-block steps that would "factor" it are left out (N=89: 6 of 8 steps), its inverse images are zero blocks and identities.
-  const int valid = (P.n - k * NB < NB) ? P.n - k * NB : NB;
+  // (A light curve of a ragged batch that is shorter than its launch set's block rows has whole blocks of padding: nse = 0,
+  //  nothing is factored, the block's z, alpha and log det are zero and its inverse images the identity.)
+  const int left = pts(P, b) - k * NB;
+  const int valid = left < 0 ? 0 : (left < NB ? left : NB);
   const int nse = __builtin_amdgcn_readfirstlane((valid + DB - 1) / DB);
   // Every wavefront meets the same two barriers per step: V_ss in LDS / block row s in LDS.
   if (wave == 0) {
@@ -803,6 +815,21 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void k_diag(PgmDev P, int k, int f
             __threadfence_system();
             P.seq_host[b] = (long long)P.outp[7];
           }
+        }
+      }
+    }
+    if (nse == 0) {                                       // a block of padding (ragged batches): zeros, and the status if it is the last
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        P.z[b * P.sVec + k * NB + lane + 64 * u] = 0.0;
+        P.alpha[b * P.sVec + k * NB + lane + 64 * u] = 0.0;
+      }
+      if (lane == 0) {
+        P.logdet[b * P.sLogdet + k] = 0.0;
+        if (k == P.nb - 1 && P.info_host) {
+          P.info_host[b] = *info;
+          __threadfence_system();
+          P.seq_host[b] = (long long)P.outp[7];
         }
       }
     }
@@ -1276,6 +1303,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
 
   const WavePos wp = wave_pos<C>();
   const double sym = (i == j) ? 1.0 : 2.0;
+  const int npts = pts(P, b);
   double* mypart = wpart + wp.wave * P.nslot;
   // acc <- sym * G = sym * (alpha alpha^T - A^-1), in place; the diagonal of G is the noise gradient
 #pragma unroll
@@ -1286,7 +1314,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
       for (int r = 0; r < 4; ++r) {
         const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
         const int gi = i * NB + m, gj = j * NB + n;
-        const bool valid = (gi < P.n) && (gj < P.n);
+        const bool valid = (gi < npts) && (gj < npts);
         const double aa = (p0 + plen == P.nb) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
         acc[ti][tj][r] = valid ? sym * (aa - acc[ti][tj][r]) : 0.0;
       }
@@ -1403,6 +1431,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   const int b = blockIdx.z, t = threadIdx.x;
   __shared__ double red[FIN_THREADS / 64];
   const int bad = P.info[b];
+  const int n = pts(P, b), cb = caller_slot(P, b);           // (ragged batches: this light curve's length and its place in the caller's arrays)
   // workgroup 0: the scalars (mll, hyper-parameter gradients); workgroups 1..: the per-point gradients
   // (mean and noise), FIN_THREADS points each -- side by side instead of one after the other
   // (a failed factorisation leaves NaN in every output, so that no caller steps on the previous evaluation's gradients)
@@ -1415,22 +1444,23 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     c_mll = (double*)P.outp[0]; c_gw = (double*)P.outp[1]; c_gmu = (double*)P.outp[2]; c_gv = (double*)P.outp[3];
     c_gnoise = (double*)P.outp[4]; c_gmean = (double*)P.outp[5]; c_info = (int*)P.outp[6];
   }
+  const int64_t cs = P.outp ? (int64_t)P.outp[8] : P.cstride;   // points per light curve slot in the caller's arrays
   if (blockIdx.x > 0) {
     if (!P.need_grad) return;
-    const double half_n = 0.5 / (double)P.n;
+    const double half_n = 0.5 / (double)n;
     const int i = ((int)blockIdx.x - 1) * FIN_THREADS + t;
     if (bad) {
-      if (i < P.n) {
+      if (i < n) {
         P.out_gmean[b * P.sVec + i] = qnan; P.out_gnoise[b * P.sVec + i] = qnan;
-        if (c_gmean) c_gmean[(int64_t)b * P.n + i] = qnan;
-        if (c_gnoise) c_gnoise[(int64_t)b * P.n + i] = qnan;
+        if (c_gmean) c_gmean[(int64_t)cb * cs + i] = qnan;
+        if (c_gnoise) c_gnoise[(int64_t)cb * cs + i] = qnan;
       }
       return;
     }
-    if (i < P.n) {
+    if (i < n) {
       const double al = P.alpha[b * P.sVec + i];
-      P.out_gmean[b * P.sVec + i] = al / (double)P.n;
-      if (c_gmean) c_gmean[(int64_t)b * P.n + i] = al / (double)P.n;
+      P.out_gmean[b * P.sVec + i] = al / (double)n;
+      if (c_gmean) c_gmean[(int64_t)cb * cs + i] = al / (double)n;
       double dsum = 0.0;
       if (P.ainv_from_tiles) {
         const int cnt = (P.nb - i / NB + P.ainv_from_tiles - 1) / P.ainv_from_tiles;      // work items of tile (jb, jb)
@@ -1440,7 +1470,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
         for (int sp = 0; sp < AINV_SPLITS; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
       }
       P.out_gnoise[b * P.sVec + i] = half_n * (al * al - dsum);
-      if (c_gnoise) c_gnoise[(int64_t)b * P.n + i] = half_n * (al * al - dsum);
+      if (c_gnoise) c_gnoise[(int64_t)cb * cs + i] = half_n * (al * al - dsum);
     }
     return;
   }
@@ -1453,23 +1483,23 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
   if (t == 0) {
     double tot = 0.0;
     for (int wv = 0; wv < FIN_THREADS / 64; ++wv) tot += red[wv];
-    const double val = bad ? qnan : -0.5 * (tot + (double)P.n * log(2.0 * PI)) / (double)P.n;
+    const double val = bad ? qnan : -0.5 * (tot + (double)n * log(2.0 * PI)) / (double)n;
     P.out_small[b * P.sOut + 0] = val;
-    if (c_mll) c_mll[b] = val;
-    if (c_info) c_info[b] = bad;
+    if (c_mll) c_mll[cb] = val;
+    if (c_info) c_info[cb] = bad;
   }
   if (!P.need_grad) return;
   // slot s of the hyper-parameter gradients in the caller's arrays: w (q), mu (q*d), v (q*d)
   auto c_slot = [&](int s, double val) {
-    if (s < P.q) { if (c_gw) c_gw[(int64_t)b * P.q + s] = val; }
-    else if (s < P.q + P.qd) { if (c_gmu) c_gmu[(int64_t)b * P.qd + (s - P.q)] = val; }
-    else if (s < P.q + 2 * P.qd) { if (c_gv) c_gv[(int64_t)b * P.qd + (s - P.q - P.qd)] = val; }
+    if (s < P.q) { if (c_gw) c_gw[(int64_t)cb * P.q + s] = val; }
+    else if (s < P.q + P.qd) { if (c_gmu) c_gmu[(int64_t)cb * P.qd + (s - P.q)] = val; }
+    else if (s < P.q + 2 * P.qd) { if (c_gv) c_gv[(int64_t)cb * P.qd + (s - P.q - P.qd)] = val; }
   };
   if (bad) {
     if (t >= 1 && t < 1 + P.q + 2 * P.qd) { P.out_small[b * P.sOut + t] = qnan; c_slot(t - 1, qnan); }
     return;
   }
-  const double half_n = 0.5 / (double)P.n;
+  const double half_n = 0.5 / (double)n;
   const int Q = P.q, QD = P.qd;
   const double* hyp = P.hyp + (int64_t)b * (PGM_MAX_QD * 3);
   const int wave = t >> 6, lane = t & 63;

@@ -48,6 +48,26 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     return out
 
 
+def mll_value_grad_ragged(x, y, mean, noise, noise_scalar, lengths, w, mu, v, dim_order=0, jitter=0.0, need_grad=True,
+                          workspace=None, max_batch=None):
+    """TEST-ONLY stand-in for ``pgmuvi_amd._hip.mll_value_grad_ragged``: every light curve on its own, by the oracle."""
+    B, S = y.shape
+    D = torch.float64
+    q = w.shape[-1]
+    d = x.reshape(B, S, -1).shape[-1]
+    out = dict(mll=torch.zeros(B, dtype=D), info=torch.zeros(B, dtype=torch.int32), g_w=torch.zeros(B, q, dtype=D),
+               g_mu=torch.zeros(B, q, d, dtype=D), g_v=torch.zeros(B, q, d, dtype=D), g_noise=torch.zeros(B, S, dtype=D),
+               g_mean=torch.zeros(B, S, dtype=D))
+    for b, n in enumerate(lengths):
+        o = mll_value_grad(x.reshape(B, S, d)[b, :n], y[b, :n], mean.expand(B, S)[b, :n], None if noise is None else noise[b, :n],
+                           None if noise_scalar is None else noise_scalar[b], w[b], mu[b], v[b], dim_order, jitter, need_grad)
+        out["mll"][b] = o["mll"]; out["info"][b] = o["info"]
+        out["g_w"][b] = o["g_w"]; out["g_mu"][b] = o["g_mu"]; out["g_v"][b] = o["g_v"]
+        out["g_noise"][b, :n] = o["g_noise"]; out["g_mean"][b, :n] = o["g_mean"]
+    out["workspace"] = None
+    return out
+
+
 class _Remember:
     """What the last stand-in evaluation was called with (for the predict stand-in)."""
     last = None

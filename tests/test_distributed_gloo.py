@@ -15,8 +15,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from pgmuvi_amd import synthetic as syn  # noqa: E402
-from pgmuvi_amd.batch import (balanced_assignment, default_chunk, evaluate_batch, gather_logliks, make_shard,  # noqa: E402
-                              shard_bounds, sharded_batch_step)
+from pgmuvi_amd.batch import (balanced_assignment, default_chunk, evaluate_batch, evaluate_ragged, gather_logliks,  # noqa: E402
+                              make_ragged_shard, make_shard, pad_curves, ragged_lengths, shard_bounds, sharded_batch_step,
+                              sharded_ragged_step)
 
 B, N = 5, 40
 
@@ -111,6 +112,85 @@ def test_strong_scaling_step_is_independent_of_the_partition(total, world):
         if nloc:
             assert torch.equal(gmu, ref["g_mu"][lo:hi])
     assert default_chunk(2048) == 512 and default_chunk(4096) == 256 and 1 <= default_chunk(16384) <= 16
+
+
+def _ragged_worker(rank, world, port, q, total, n_lo, n_hi):
+    """Ragged batch: light curves dealt to the ranks by N^3 (``make_ragged_shard``), each rank evaluates its own through the
+    ragged entry point (oracle stand-in), one all_gather puts the values back into the batch's order."""
+    import _oracle_backend as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = make_ragged_shard(total, rank, world, n_lo, n_hi)
+    out, ll = sharded_ragged_step(shard, chunk=3, _compute=ob.mll_value_grad_ragged)
+    q.put((rank, shard["index"], ll, out.get("g_w"), [g.clone() for g in out.get("g_noise", [])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,world", [(7, 2), (2, 3)])
+def test_ragged_batch_over_ranks_is_the_single_process_result(total, world):
+    """Unequal N across ranks: ``balanced_assignment`` on N^3 decides who evaluates what, every rank
+    ends with the same vector of log-likelihoods in the batch's order as one process evaluating everything -- also with a
+    rank that owns nothing (2 light curves over 3 ranks)."""
+    import _oracle_backend as ob
+    n_lo, n_hi = 24, 70
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q, total, n_lo, n_hi)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    whole = make_ragged_shard(total, 0, 1, n_lo, n_hi)
+    assert whole["index"] == list(range(total)) and whole["lengths"] == ragged_lengths(total, n_lo, n_hi)
+    assert len(set(whole["lengths"])) > 1                             # (ragged indeed)
+    ref, ref_ll = sharded_ragged_step(whole, _compute=ob.mll_value_grad_ragged)
+    assert ref_ll.shape == (total,)
+    # the deal: every light curve exactly once, heaviest-first onto the lightest rank
+    owner = balanced_assignment([float(n) ** 3 for n in whole["lengths"]], world)
+    assert sorted(i for g in got for i in g[1]) == list(range(total))
+    for rank, index, ll, gw, gnoise in got:
+        assert index == [i for i in range(total) if owner[i] == rank]
+        assert torch.equal(ll, ref_ll)
+        for k, i in enumerate(index):
+            assert torch.equal(gw[k], ref["g_w"][i])
+            assert gnoise[k].shape == (whole["lengths"][i],) and torch.equal(gnoise[k], ref["g_noise"][i])
+    # each value is the light curve's own (the equal-length evaluation of that light curve alone)
+    c = whole["curves"][total - 1]
+    n = whole["lengths"][total - 1]
+    alone = ob.mll_value_grad(c["x"].reshape(n, 1), c["y"], c["mean"].expand(n), c["noise"], None, c["w"], c["mu"].reshape(4, 1),
+                              c["v"].reshape(4, 1))
+    assert torch.equal(alone["mll"], ref_ll[total - 1])
+
+
+def test_ragged_launch_sets_follow_the_cost_model():
+    """``pgm_ragged_plan`` (host only): light curves are grouped by block-row count, longest first; a short group joins the
+    set above it only where padding is cheaper than a launch set of its own; sets never exceed the workspace's batch."""
+    from pgmuvi_amd import _hip
+    # 9 block-row counts with 57 light curves each (512 x N ~ U(1024, 2048)): every count its own set
+    lengths = [1025 + 128 * k for k in range(8) for _ in range(57)] + [900] * 57
+    set_of, nbs = _hip.ragged_plan(lengths, 512)
+    assert nbs == [16, 15, 14, 13, 12, 11, 10, 9, 8] and len(set(set_of)) == 9
+    assert all(nbs[s2] == (n + 127) // 128 for s2, n in zip(set_of, lengths))
+    # a lone light curve of 15 block rows rides with the 16-block-row set; 40 of them do not (40 * (16^3 - 15^3) * 0.044 > 15 * 60)
+    set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900], 512)
+    assert nbs == [16] and set(set_of) == {0}
+    set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900] * 40, 512)
+    assert nbs == [16, 15]
+    # order of the caller is kept inside a set, and the answer does not depend on it
+    set_of, nbs = _hip.ragged_plan([200, 2300, 640, 2300, 130], 512)
+    assert nbs[0] == 18 and set_of[1] == set_of[3] == 0
+    # more members than the workspace holds: split
+    set_of, nbs = _hip.ragged_plan([512] * 20, 8)
+    assert nbs == [4, 4, 4] and [set_of.count(k) for k in range(3)] == [8, 8, 4]
+    with pytest.raises(RuntimeError):
+        _hip.ragged_plan([0, 5], 4)
 
 
 def test_partitioning_rules():

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 from oracle import sm_mll_oracle as orc
 from pgmuvi_amd import _hip, synthetic as syn
 from pgmuvi_amd import gpytorch as g
-from pgmuvi_amd.batch import evaluate_batch
+from pgmuvi_amd.batch import evaluate_batch, evaluate_ragged, pad_curves
 
 D = torch.float64
 MLL_TOL = 1e-9
@@ -179,6 +179,99 @@ def test_batched_equals_singles_and_oracle(dev):
         assert abs(float(val) - float(out["mll"][i])) < MLL_TOL
         for p in ("w", "mu", "v"):
             assert _rel(out[f"g_{p}"][i].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
+def _ragged_curves(lengths, first=0):
+    curves = []
+    for k, n in enumerate(lengths):
+        (t, y, e), per = syn.cfg3_lightcurve(first + k, n_obs=n)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        curves.append(dict(x=t.double(), y=y.double(), noise=e.double() ** 2, mean=h["mean"], w=h["w"], mu=h["mu"].reshape(4, 1),
+                           v=h["v"].reshape(4, 1)))
+    return curves
+
+
+def test_ragged_batch_equals_singles_and_oracle(dev):
+    """SURVEY.md section 8e, ragged N: 24 light curves with N in [200, 2300] in ONE call of the ragged entry point -- sorted
+    by block rows, run in launch sets that share a chain length, shorter members padded with identity blocks (whole block
+    rows of them where lengths joined a longer set).  Every value equals the light curve's own single evaluation bit for
+    bit (the padding adds exact zeros to the sums of the value), every gradient equals it to rounding (a set's
+    inverse/gradient pass is split for the set's block rows) and the oracle at the suite's tolerances."""
+    rng = np.random.default_rng(11)
+    lengths = [int(v) for v in rng.integers(200, 2301, size=24)]
+    lengths[3], lengths[17] = 2300, 200                                  # (the ends of the range are in)
+    curves = _ragged_curves(lengths)
+    set_of, nbs = _hip.ragged_plan(lengths, 24)
+    assert len(nbs) < len(set((n + 127) // 128 for n in lengths))        # (some lengths joined a longer set: padded block rows)
+    out = evaluate_ragged(curves, device=dev)
+    torch.cuda.synchronize()
+    assert int(out["info"].abs().max()) == 0
+    for b, (c, n) in enumerate(zip(curves, lengths)):
+        single = _hip_eval(dev, c["x"].reshape(n, 1), c["y"], c["mean"], c["noise"], c["w"], c["mu"], c["v"])
+        assert float(single["mll"]) == float(out["mll"][b]), (b, n)      # bit for bit
+        for p in ("w", "mu", "v"):
+            assert _rel(single[f"g_{p}"].reshape(-1), out[f"g_{p}"][b].reshape(-1)) < 1e-10, (b, n, p)
+        assert out["g_noise"][b].shape == (n,) and _rel(single["g_noise"], out["g_noise"][b]) < 1e-10
+        assert _rel(single["g_mean"], out["g_mean"][b]) < 1e-10
+        val, gr = orc.mll_value_grad_closed_form(c["x"].reshape(n, 1), c["y"], c["mean"].expand(n), c["noise"], c["w"], c["mu"], c["v"])
+        assert abs(float(val) - float(out["mll"][b])) < MLL_TOL, (b, n)
+        for p in ("w", "mu", "v"):
+            assert _rel(out[f"g_{p}"][b].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, (b, n, p)
+        assert _rel(out["g_noise"][b], gr["noise"]) < GRAD_RTOL and _rel(out["g_mean"][b], gr["mean"]) < GRAD_RTOL
+    # the same call again (nothing uploaded: same lengths) and with a workspace that holds 5 light curves (sets are split)
+    again = evaluate_ragged(curves, device=dev)
+    small = evaluate_ragged(curves, device=dev, chunk=5)
+    torch.cuda.synchronize()
+    assert torch.equal(again["mll"], out["mll"]) and torch.equal(again["g_mu"], out["g_mu"])
+    assert torch.equal(small["mll"], out["mll"])
+    for p in ("w", "mu", "v"):
+        assert _rel(small[f"g_{p}"].reshape(-1), out[f"g_{p}"].reshape(-1)) < 1e-10
+
+
+def test_ragged_set_is_bit_for_bit_the_equal_length_batch(dev):
+    """Inside a launch set every light curve runs the schedule of the set's (block rows, members): a member whose own block
+    rows are the set's gets, gradients included, the bits of the equal-length batched call of the same shape; and padded
+    arrays straight from the caller (no list of curves) give the same as the list form."""
+    lengths = [1500, 1290, 1409, 1536, 1300, 1480]                       # 12, 11, 12, 12, 11, 12 block rows -> one set of 12
+    set_of, nbs = _hip.ragged_plan(lengths, 16)
+    assert nbs == [12] and set(set_of) == {0}
+    curves = _ragged_curves(lengths, first=40)
+    out = evaluate_ragged(curves, device=dev)
+    padded, lens = pad_curves(curves, device=dev)
+    out2 = evaluate_ragged(padded=padded, lengths=lens)
+    torch.cuda.synchronize()
+    assert torch.equal(out["mll"], out2["mll"]) and torch.equal(out["g_v"], out2["g_v"])
+    for b in (0, 3):
+        c, n = curves[b], lengths[b]
+        rep = lambda t: t.to(dev).unsqueeze(0).repeat(len(lengths), *([1] * t.dim())).contiguous()
+        eq = _hip.mll_value_grad(rep(c["x"].reshape(n, 1)), rep(c["y"]), rep(c["mean"].expand(n)), rep(c["noise"]), None,
+                                 rep(c["w"]), rep(c["mu"]), rep(c["v"]), 0, 0.0, True)
+        torch.cuda.synchronize()
+        assert float(eq["mll"][b]) == float(out["mll"][b])
+        for p in ("w", "mu", "v"):
+            assert torch.equal(eq[f"g_{p}"][b], out[f"g_{p}"][b]), (b, p)
+        assert torch.equal(eq["g_noise"][b], out["g_noise"][b]) and torch.equal(eq["g_mean"][b], out["g_mean"][b])
+
+
+def test_ragged_batch_reports_the_member_that_fails(dev):
+    """A member whose matrix is not positive definite: its ``info`` is the pivot, its outputs NaN; the others are untouched."""
+    lengths = [300, 700, 520, 150]
+    curves = _ragged_curves(lengths, first=60)
+    curves[2]["noise"] = -5.0 * torch.ones(lengths[2], dtype=D)
+    out = evaluate_ragged(curves, device=dev)
+    good = evaluate_ragged([curves[0], curves[1], curves[3]], device=dev)
+    torch.cuda.synchronize()
+    info = out["info"].cpu().tolist()
+    assert info[2] > 0 and [info[0], info[1], info[3]] == [0, 0, 0]
+    assert math.isnan(float(out["mll"][2])) and bool(torch.isnan(out["g_w"][2]).all()) and bool(torch.isnan(out["g_noise"][2]).all())
+    for a, b in ((0, 0), (1, 1), (3, 2)):
+        assert abs(float(out["mll"][a]) - float(good["mll"][b])) < 1e-13
+    # argument checks of the entry point: a length beyond the pitch, an empty light curve
+    padded, lens = pad_curves(curves[:2], device=dev)
+    with pytest.raises(ValueError):
+        evaluate_ragged(padded=padded, lengths=[lens[0], padded["y"].shape[1] + 1])
+    with pytest.raises(ValueError):
+        evaluate_ragged(padded=padded, lengths=[0, lens[1]])
 
 
 def test_dense_kernel_entry_point(dev):
