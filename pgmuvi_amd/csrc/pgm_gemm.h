@@ -72,7 +72,7 @@ template <class C>
 __device__ __forceinline__ WavePos wave_pos() {
   WavePos p;
   p.lane = threadIdx.x & 63;
-  p.wave = threadIdx.x >> 6;
+  p.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: the sub-tile's place stays in scalar registers)
   p.m0 = (p.wave / C::WAVES_N) * C::WM;
   p.n0 = (p.wave % C::WAVES_N) * C::WN;
   return p;
@@ -183,6 +183,94 @@ __device__ __forceinline__ void gemm_direct(int nkb, PtrFn&& ptrs, v4d (&acc)[C:
   }
 }
 
+// Symmetric tiles (round 4).  A diagonal tile of A^-1 = V^T V -- operands A and B are the same block column -- equals its own
+// transpose, and with the rows of a sub-tile dealt round-robin to the MFMA tiles (above) MFMA tile (tj, ti) of a diagonal
+// 64x64 quadrant is exactly the transpose of MFMA tile (ti, tj).  So the four wavefronts of a 128x128 tile share the work as
+//   wave 0: quadrant (0, 0), MFMA tiles ti <= tj (10 of 16)      wave 1: quadrant (0, 64), MFMA tile rows ti = 0, 1 (8)
+//   wave 3: quadrant (64, 64), the same                          wave 2: quadrant (0, 64), MFMA tile rows ti = 2, 3 (8)
+// and quadrant (64, 0) is nobody's: 36 MFMAs per k-step instead of 64, at most 10 on any SIMD (0.625 of the time of a full tile).
+// The caller weights the tiles in whatever it contracts them with (2 for a tile that stands for its mirror image, 1 on the
+// diagonal).  SH: which MFMA tiles of the wavefront's 4x4 are computed; the others are left as they are.
+enum TileShape { SH_FULL = 0, SH_UPPER = 1, SH_ROWS_LO = 2, SH_ROWS_HI = 3 };
+template <int SH> __host__ __device__ constexpr bool shape_has(int ti, int tj) {
+  return SH == SH_FULL ? true : SH == SH_UPPER ? ti <= tj : SH == SH_ROWS_LO ? ti < 2 : ti >= 2;
+}
+__device__ __forceinline__ int shape_tj_lo(int shape, int ti) {       // the computed MFMA tiles of row ti are tj = shape_tj_lo .. 3
+  return shape == SH_FULL ? 0 : shape == SH_UPPER ? ti : shape == SH_ROWS_LO ? (ti < 2 ? 0 : 4) : (ti >= 2 ? 0 : 4);
+}
+template <class C, int SH, class PtrFn>
+__device__ __forceinline__ void gemm_direct_shaped(const WavePos wp, int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late) {
+  static_assert(C::DIRECT && C::TM == 4 && C::TN == 4, "shaped tiles: the direct 64x64-per-wavefront form");
+  constexpr int PD = C::PF, TM = C::TM, TN = C::TN, KS = NB / 4;
+  constexpr int TA = (SH == SH_ROWS_LO || SH == SH_ROWS_HI) ? 2 : TM, A0 = SH == SH_ROWS_HI ? 2 : 0;   // A fragments: rows A0 .. A0 + TA - 1
+  const int g = wp.lane >> 4, i = wp.lane & 15;
+  const int ca = (wp.m0 + TM * i + A0) * 8, cb = (wp.n0 + TN * i) * 8;
+  auto block = [&](int kb) {
+    const double* pa; const double* pb; int64_t lda, ldb;
+    ptrs(kb, pa, lda, pb, ldb);
+    OperandBlock o;
+    o.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pa), 0, 0x7fffffff, 0x00027000);
+    o.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pb), 0, 0x7fffffff, 0x00027000);
+    o.voa = g * (int)lda * 8 + ca; o.vob = g * (int)ldb * 8 + cb;
+    o.sa = 4 * (int)lda * 8; o.sb = 4 * (int)ldb * 8;
+    return o;
+  };
+  double a[PD][TA], b[PD][TN];
+  auto load = [&](int u, int ks) {
+    const OperandBlock o = block(ks / KS);
+    const int kr = ks % KS;
+    load_frag<TA>(o.ra, o.voa, kr * o.sa, a[u]); load_frag<TN>(o.rb, o.vob, kr * o.sb, b[u]);
+  };
+  const int nks = nkb * KS;
+#pragma unroll
+  for (int u = 0; u < PD; ++u) load(u, u);
+  if (negate_late) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TN; ++tj) if (shape_has<SH>(ti, tj)) acc[ti][tj] = -acc[ti][tj];
+  }
+  for (int ks0 = 0; ks0 < nks; ks0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+#pragma unroll
+      for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj)
+          if (shape_has<SH>(ti, tj))                           // (folded when the loops are unrolled)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][(ti - A0) & (TA - 1)], b[u][tj], acc[ti][tj], 0, 0, 0);
+      if (ks0 + u + PD < nks) load(u, ks0 + u + PD);
+    }
+  }
+}
+
+// the accumulators of a shaped wavefront: its computed MFMA tiles start from +C (c != null; negated inside the loop) or from
+// zero; the others are cleared AFTER the loop by acc_clear_outside (so that they are dead registers while it runs)
+template <class C, int SH>
+__device__ __forceinline__ void acc_init_shaped(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN], const WavePos wp) {
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti) {
+    bool any = false;
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) any = any || shape_has<SH>(ti, tj);
+    if (!any) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double x[C::TN];
+      if (c) load_run<C::TN>(c + (int64_t)acc_row<C>(wp, ti, r) * ldc + acc_col<C>(wp, 0), x);
+#pragma unroll
+      for (int tj = 0; tj < C::TN; ++tj) if (shape_has<SH>(ti, tj)) acc[ti][tj][r] = c ? x[tj] : 0.0;
+    }
+  }
+}
+template <class C, int SH>
+__device__ __forceinline__ void acc_clear_outside(v4d (&acc)[C::TM][C::TN]) {
+#pragma unroll
+  for (int ti = 0; ti < C::TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < C::TN; ++tj) if (!shape_has<SH>(ti, tj)) acc[ti][tj] = v4d{0.0, 0.0, 0.0, 0.0};
+}
+
 // ptrs(kb, pa, lda, pb, ldb): operand tile pointers of k-block kb: A tile is
 // NB x BM at pa (row pitch lda), B tile NB x BN at pb.
 // bsplit != 0: the right half of the B tile (columns BN/2..BN-1) sits bsplit columns further along in memory (two
@@ -268,8 +356,8 @@ __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn
 
 // acc = scale * C; C tile at c, pitch ldc
 template <class C, bool NT = false>
-__device__ __forceinline__ void acc_load_scaled(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN], double scale) {
-  const WavePos wp = wave_pos<C>();
+__device__ __forceinline__ void acc_load_scaled(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN], double scale,
+                                                const WavePos wp = wave_pos<C>()) {
   if constexpr (C::DIRECT) {       // a lane's TN columns of one row are contiguous: 16-byte accesses, 16 TN 8-byte runs per row
 #pragma unroll
     for (int ti = 0; ti < C::TM; ++ti)
@@ -295,7 +383,9 @@ template <class C>
 __device__ __forceinline__ void acc_load_neg(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C>(c, ldc, acc, -1.0); }
 // acc = +C, to be negated by gemm_tn(..., negate_late = true) once the first operand chunks are on their way
 template <class C, bool NT = false>
-__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN]) { acc_load_scaled<C, NT>(c, ldc, acc, 1.0); }
+__device__ __forceinline__ void acc_load_raw(const double* __restrict__ c, int64_t ldc, v4d (&acc)[C::TM][C::TN], const WavePos wp = wave_pos<C>()) {
+  acc_load_scaled<C, NT>(c, ldc, acc, 1.0, wp);
+}
 template <class C>
 __device__ __forceinline__ void acc_negate(v4d (&acc)[C::TM][C::TN]) {
 #pragma unroll

@@ -64,6 +64,7 @@ struct PgmDev {
   const double *x, *y, *mean, *noise, *noise_scalar_dev, *w, *mu, *v;
   double *mll, *g_w, *g_mu, *g_v, *g_noise, *g_mean;
   int* info_out;
+  int items_kc;       // k-blocks per work item of `items` (the split length its table was made with)
   int ainv_from_tiles; // k-blocks per work item (0 = off): diag(A^-1) is taken from the accumulators of the (j, j) tiles' work items
                       //    in the inverse/gradient launch (item number s of the tile -> dpart row s) and the separate column-sum
                       //    pass over V is skipped
@@ -86,8 +87,11 @@ struct pgm_ws {
   int* ragged_tab;       // device [2 * ragged_cap]: nvec | cmap of the last ragged call, in its sorted order (grown on demand)
   int ragged_cap;
   std::vector<int> ragged_host;   // what ragged_tab holds (a repeated call with the same lengths uploads nothing)
-  int4* items;           // device copy of the work-item table
-  std::vector<int4> items_host;
+  // work-item tables of the inverse/gradient pass, one per (block rows, batch class, epilogue weight) ever asked for: built once,
+  // never rewritten (captured graphs and the launch sets of a ragged batch keep pointing at theirs)
+  struct ItemsEntry { int nb, sim_batch, kc, count; double epi; int4* dev; };
+  std::vector<ItemsEntry> items_cache;
+  int4* items;           // the table of the current call (one of items_cache)
   int items_nb, items_batch, items_count, items_cap, items_kc;
   int64_t part_rows;     // rows of `partials` per problem
   double items_epi, early_epi;  // epilogue weight the two work lists were split for (spectral mixture 3, generic kernels 15)

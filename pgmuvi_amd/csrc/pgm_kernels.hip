@@ -10,6 +10,9 @@ namespace {
 
 constexpr double PI = 3.14159265358979323846;
 constexpr double TWO_PI_SQ = 2.0 * PI * PI;
+// The per-point factor x_i v_qd is staged as x_i v_qd pi sqrt(2): the Gaussian envelope exp(-2 pi^2 (x_i v - x_j v)^2) is then
+// exp(-(difference of the staged values)^2) -- the same scale-then-subtract form as GPyTorch's, one multiplication less per pair.
+constexpr double PI_SQRT2 = 4.44288293815836624702;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -21,8 +24,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // polynomial on |r| <= ln2/2 (truncation 4e-18), scaled by 2^n with v_ldexp_f64 (underflows to 0
 // by itself).  19 instructions against ~35 for the library call; every N^2 pass pays one per
 // (pair, mixture, dimension).
+// (No clamp in front: for x far below the underflow threshold n is a large negative number, the conversion to int saturates
+//  and v_ldexp_f64 returns 0 -- the value the clamp to -800 produced, for one instruction less per pair and mixture.)
 __device__ __forceinline__ double exp_neg(double x) {
-  x = fmax(x, -800.0);                                    // 2^-1154: ldexp flushes to 0, n stays an int
   const double n = rint(x * 1.4426950408889634074);
   double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
   r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void k_precompute(PgmDev P) {
       sincospi(2.0 * (xi * mu), &s, &c);
       pre[(int64_t)(qd * 3 + 0) * P.np + i] = c;
       pre[(int64_t)(qd * 3 + 1) * P.np + i] = s;
-      pre[(int64_t)(qd * 3 + 2) * P.np + i] = xi * v;
+      pre[(int64_t)(qd * 3 + 2) * P.np + i] = xi * v * PI_SQRT2;
     }
   }
   const int64_t vi = (int64_t)b * P.sVec + i;
@@ -152,7 +156,7 @@ __device__ __forceinline__ double sm_pair(const double* rowd, const double* cold
     for (int dd = 0; dd < D; ++dd) {
       const int qd = q * D + dd;
       const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-      const double e = exp_neg(-TWO_PI_SQ * ds * ds);
+      const double e = exp_neg(-(ds * ds));
       const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
                         rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
       if (ORDER == 0) S[dd] += wl[q] * e * cc; else prod *= e * cc;
@@ -191,15 +195,18 @@ __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* row
       const double wq = wl[q];
       const double* cq = cold + q * 3 * NB;
       const double* rq = rowd + q * 3 * NB;
-      const double cc0 = cq[c2], cc1 = cq[c2 + 1], cs0 = cq[NB + c2], cs1 = cq[NB + c2 + 1];
+      // (the mixture weight rides on the thread's column factors: 4 multiplications per mixture instead of one per pair.
+      //  24 fp64 instructions per pair and mixture are left -- the difference, its square, 19 for the exponential, 3 for the
+      //  weighted cosine of the angle difference and its accumulation)
+      const double cc0 = wq * cq[c2], cc1 = wq * cq[c2 + 1], cs0 = wq * cq[NB + c2], cs1 = wq * cq[NB + c2 + 1];
       const double cv0 = cq[2 * NB + c2], cv1 = cq[2 * NB + c2 + 1];
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr) {
         const int m = row0 + rg + 4 * rr;
         const double rc = rq[m], rs = rq[NB + m], rv = rq[2 * NB + m];
         const double d0 = rv - cv0, d1 = rv - cv1;
-        acc[rr][0] = __builtin_fma(wq * exp_neg(-TWO_PI_SQ * d0 * d0), __builtin_fma(rc, cc0, rs * cs0), acc[rr][0]);
-        acc[rr][1] = __builtin_fma(wq * exp_neg(-TWO_PI_SQ * d1 * d1), __builtin_fma(rc, cc1, rs * cs1), acc[rr][1]);
+        acc[rr][0] = __builtin_fma(exp_neg(-(d0 * d0)), __builtin_fma(rc, cc0, rs * cs0), acc[rr][0]);
+        acc[rr][1] = __builtin_fma(exp_neg(-(d1 * d1)), __builtin_fma(rc, cc1, rs * cs1), acc[rr][1]);
       }
     }
 #pragma unroll
@@ -945,6 +952,15 @@ __device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds
   tri_decode(pair, s1, s2);
   const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
   const double* Bp = P.crit + (int64_t)b * NB * NB + s1 * LOOK_SLAB;
+  const WavePos wp = wave_pos<C>();
+  // the 16x16 block this workgroup updates is asked for now, in the shadow of the solve (it is final since the launch before:
+  // asked for behind the solve, as in rounds 2-3, its round trip sat on the chain once per block row)
+  double* Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + s1 * LOOK_SLAB + (wp.lane >> 4)) * P.ld + (k + 1) * NB + s2 * LOOK_SLAB + (wp.lane & 15);
+  v4d d = {0.0, 0.0, 0.0, 0.0};
+  if (wp.wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = Cd[(int64_t)4 * r * P.ld];
+  }
   v4d acc[C::TM][C::TN];
   acc_zero<C>(acc);
   gemm_tn<C>(lds, 1, [&](int, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
@@ -952,7 +968,6 @@ __device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds
   }, acc, (s2 - s1) * LOOK_SLAB - LOOK_SLAB);
   // (gemm_tn ends on a barrier: the staging area is free) the two solved slabs as one [k][32] image
   constexpr int PX = 2 * LOOK_SLAB + 16;
-  const WavePos wp = wave_pos<C>();
 #pragma unroll
   for (int ti = 0; ti < C::TM; ++ti)
 #pragma unroll
@@ -962,10 +977,7 @@ __device__ __forceinline__ void lookahead_diag_tile(const PgmDev& P, double* lds
   // applies to this block (acc_load_neg, MFMAs with k ascending, store of -acc), so the factor -- and with it the value --
   // is bit for bit what the schedules without look-ahead produce
   if (wp.wave == 0) {
-    double* Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + s1 * LOOK_SLAB + (wp.lane >> 4)) * P.ld + (k + 1) * NB + s2 * LOOK_SLAB + (wp.lane & 15);
-    v4d d;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) d[r] = -Cd[(int64_t)4 * r * P.ld];
+    d = -d;
 #pragma unroll 8
     for (int kk = 0; kk < NB / 4; ++kk) {
       const int krow = kk * 4 + (wp.lane >> 4);
@@ -1216,8 +1228,7 @@ __device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, 
 // diag(A^-1) straight from the work items of the (j, j) tiles of A^-1: the lanes that hold diagonal elements write this item's
 // share to its row of dpart (item number = k-blocks before it / k-blocks per item); k_finalize sums the rows the tile has
 template <class C>
-__device__ __forceinline__ void ainv_diag_from_tile(const PgmDev& P, int b, int j, int p0, const v4d (&acc)[C::TM][C::TN]) {
-  const WavePos wp = wave_pos<C>();
+__device__ __forceinline__ void ainv_diag_from_tile(const PgmDev& P, int b, int j, int p0, const v4d (&acc)[C::TM][C::TN], const WavePos wp) {
   if (wp.m0 != wp.n0) return;
 #pragma unroll
   for (int ti = 0; ti < C::TM; ++ti)
@@ -1258,19 +1269,43 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   const double* Dv = P.Dinv + b * P.sDinv;
   const int64_t ld = P.ld;
   v4d acc[C::TM][C::TN];
+  // A diagonal tile (i == j) is symmetric: its four wavefronts compute the upper MFMA tiles of the two diagonal quadrants and
+  // half of quadrant (0, 64) each, nobody quadrant (64, 0) (pgm_gemm.h, "Symmetric tiles"): 0.625 of a full tile's time, for
+  // the multiply loop and for the gradient epilogue behind it.  (Whole tiles only: the quarter-tile form of short light curves
+  // keeps full tiles.)
+  WavePos wp = wave_pos<C>();
+  int shape = SH_FULL;
+  if constexpr (SUB == 1 && C::DIRECT) {
+    if (i == j) {
+      shape = (wp.wave == 0 || wp.wave == 3) ? SH_UPPER : (wp.wave == 1 ? SH_ROWS_LO : SH_ROWS_HI);
+      if (wp.wave == 2) { wp.m0 = 0; wp.n0 = C::WN; }
+    }
+    shape = __builtin_amdgcn_readfirstlane(shape);
+  }
   // (the sum over the block rows before p0 was left in R, negated, by the sweep's spare filler workgroups)
   const bool cont = (item.w & LAUUM_LOAD) != 0;
-  if (cont) acc_load_raw<C>(P.R + ((int64_t)i * NB + mo) * ld + j * NB + no, ld, acc);   // (negated inside gemm_tn)
-  else acc_zero<C>(acc);
-  gemm_tn<C>(lds, plen, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
+  const double* Rt = cont ? P.R + ((int64_t)i * NB + mo) * ld + j * NB + no : nullptr;
+  auto operands = [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = p0 + kb;
     if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB + mo; lda = ld; }
     else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB + mo; lda = NB; }
     if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB + no; ldb = ld; }
     else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + no; ldb = NB; }
-  }, acc, 0, cont);
+  };
+  auto full_tile = [&]() {
+    if (cont) acc_load_raw<C>(Rt, ld, acc, wp); else acc_zero<C>(acc);      // (negated inside gemm_tn)
+    gemm_tn<C>(lds, plen, operands, acc, 0, cont);
+  };
+  if constexpr (SUB == 1 && C::DIRECT) {
+    if (shape == SH_FULL) full_tile();
+    else if (shape == SH_UPPER) { acc_init_shaped<C, SH_UPPER>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_UPPER>(wp, plen, operands, acc, cont); acc_clear_outside<C, SH_UPPER>(acc); }
+    else if (shape == SH_ROWS_LO) { acc_init_shaped<C, SH_ROWS_LO>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_ROWS_LO>(wp, plen, operands, acc, cont); acc_clear_outside<C, SH_ROWS_LO>(acc); }
+    else { acc_init_shaped<C, SH_ROWS_HI>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_ROWS_HI>(wp, plen, operands, acc, cont); acc_clear_outside<C, SH_ROWS_HI>(acc); }
+  } else {
+    full_tile();
+  }
 
-  if constexpr (SUB == 1) { if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc); }
+  if constexpr (SUB == 1) { if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc, wp); }
   // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
   const int Q = P.q;
   constexpr int QC = (EPI_SLOTS - D) / (3 * D);          // mixtures staged at once
@@ -1301,7 +1336,6 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
   for (int e = threadIdx.x; e < 4 * P.nslot; e += NTHREADS) wpart[e] = 0.0;
   if (nchunks == 1) stage(0, Q); else __syncthreads();
 
-  const WavePos wp = wave_pos<C>();
   const double sym = (i == j) ? 1.0 : 2.0;
   const int npts = pts(P, b);
   double* mypart = wpart + wp.wave * P.nslot;
@@ -1316,10 +1350,64 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
         const int gi = i * NB + m, gj = j * NB + n;
         const bool valid = (gi < npts) && (gj < npts);
         const double aa = (p0 + plen == P.nb) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
-        acc[ti][tj][r] = valid ? sym * (aa - acc[ti][tj][r]) : 0.0;
+        // (shaped diagonal tile: an MFMA tile above the diagonal stands for its mirror image too, the ones that were not computed count nothing)
+        const double wt = shape == SH_FULL ? sym : (tj < shape_tj_lo(shape, ti) ? 0.0 : (shape == SH_UPPER && ti == tj) ? 1.0 : 2.0);
+        acc[ti][tj][r] = (valid && wt != 0.0) ? wt * (aa - acc[ti][tj][r]) : 0.0;
       }
+  // One input dimension, every mixture staged at once (the usual case): mixtures outermost and the whole sub-tile unrolled
+  // inside -- accumulator elements are addressed statically (no copy of a row of G per step), the three sums are reduced
+  // across the wavefront once per mixture instead of once per mixture and MFMA-tile row, the time difference and the row's
+  // factors are read once per (row, mixture).  31 fp64 instructions per pair and mixture (45 in the general loop below):
+  // difference, its square, 19 for the exponential, 4 for cosine and sine of the angle difference, 5 for the three sums.
+  bool done = false;
+  if constexpr (D == 1) {
+    if (nchunks == 1) {
+      done = true;
+      const double* rowx = rowd + 3 * Q * NB;
+      const double* colx = cold + 3 * Q * NB;
 #pragma unroll 1
-  for (int ti = 0; ti < C::TM; ++ti) {
+      for (int q = 0; q < Q; ++q) {
+        const double* rq = rowd + q * 3 * NB;
+        const double* cq = cold + q * 3 * NB;
+        double gw = 0.0, gmu = 0.0, gv = 0.0;
+#pragma unroll
+        for (int ti = 0; ti < C::TM; ++ti) {
+          const int tj_lo = shape_tj_lo(shape, ti);          // (uniform) the MFMA tiles of this row that count: tj_lo .. TN-1
+          if (tj_lo >= C::TN) continue;
+          double rc[4], rs[4], rv[4], rx[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mo + acc_row<C>(wp, ti, r);
+            rc[r] = rq[m]; rs[r] = rq[NB + m]; rv[r] = rq[2 * NB + m]; rx[r] = rowx[m];
+          }
+#pragma unroll
+          for (int tj = 0; tj < C::TN; ++tj) {
+            if (tj < tj_lo) continue;
+            const int n = no + acc_col<C>(wp, tj);
+            const double cc_ = cq[n], cs_ = cq[NB + n], cv = cq[2 * NB + n], cx = colx[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double ds = rv[r] - cv;
+              const double GE = acc[ti][tj][r] * exp_neg(-(ds * ds));
+              const double CC = __builtin_fma(rc[r], cc_, rs[r] * cs_);
+              const double SN = __builtin_fma(rs[r], cc_, -(rc[r] * cs_));
+              const double tau = rx[r] - cx;
+              const double t = GE * tau;
+              gw = __builtin_fma(GE, CC, gw);
+              gmu = __builtin_fma(t, SN, gmu);
+              gv = __builtin_fma(t, CC * tau, gv);
+            }
+          }
+        }
+        gw = wave_sum(gw); gmu = wave_sum(gmu); gv = wave_sum(gv);
+        if (wp.lane == 0) { mypart[q] += gw; mypart[Q + q] += gmu; mypart[2 * Q + q] += gv; }
+      }
+    }
+  }
+#pragma unroll 1
+  for (int ti = 0; ti < C::TM && !done; ++ti) {
+    const int tj_lo = shape_tj_lo(shape, ti);               // (uniform) the MFMA tiles of this row that count: tj_lo .. TN-1
+    if (tj_lo >= C::TN) continue;
     double Sd[D][C::TN][4];
     v4d Gw[C::TN];                 // this ti's row of G tiles (runtime ti: select statically)
 #pragma unroll
@@ -1343,16 +1431,18 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
           for (int dd = 0; dd < D; ++dd) {
             const int qd = ql * D + dd;
 #pragma unroll
-            for (int tj = 0; tj < C::TN; ++tj)
+            for (int tj = 0; tj < C::TN; ++tj) {
+              if (tj < tj_lo) continue;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
                 const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-                const double e = exp_neg(-TWO_PI_SQ * ds * ds);
+                const double e = exp_neg(-(ds * ds));
                 const double cc = rowd[(qd * 3 + 0) * NB + m] * cold[(qd * 3 + 0) * NB + n] +
                                   rowd[(qd * 3 + 1) * NB + m] * cold[(qd * 3 + 1) * NB + n];
                 Sd[dd][tj][r] += wl[q0 + ql] * e * cc;
               }
+            }
           }
         }
       }
@@ -1368,7 +1458,8 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) { gmu[dd] = 0.0; gv[dd] = 0.0; }
 #pragma unroll
-        for (int tj = 0; tj < C::TN; ++tj)
+        for (int tj = 0; tj < C::TN; ++tj) {
+          if (tj < tj_lo) continue;                            // (a row of a shaped diagonal tile: only the tiles that were computed)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
@@ -1379,7 +1470,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
               const double rc = rowd[(qd * 3 + 0) * NB + m], rsn = rowd[(qd * 3 + 1) * NB + m];
               const double cc_ = cold[(qd * 3 + 0) * NB + n], cs_ = cold[(qd * 3 + 1) * NB + n];
               const double ds = rowd[(qd * 3 + 2) * NB + m] - cold[(qd * 3 + 2) * NB + n];
-              E[dd] = exp_neg(-TWO_PI_SQ * ds * ds);
+              E[dd] = exp_neg(-(ds * ds));
               CC[dd] = rc * cc_ + rsn * cs_;
               SN[dd] = rsn * cc_ - rc * cs_;
               TAU[dd] = rowx[dd * NB + m] - colx[dd * NB + n];
@@ -1403,6 +1494,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
               if (ORDER != 0) gw += G * E[0] * CC[0] * E[1 % D] * CC[1 % D];
             }
           }
+        }
         gw = wave_sum(gw);
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) { gmu[dd] = wave_sum(gmu[dd]); gv[dd] = wave_sum(gv[dd]); }
@@ -1587,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_pred_cross(PgmDev P, const double* __re
     sincospi(2.0 * (xj * hyp[P.q + qd]), &s, &co);
     cold[(qd * 3 + 0) * NB + c] = co;
     cold[(qd * 3 + 1) * NB + c] = s;
-    cold[(qd * 3 + 2) * NB + c] = xj * hyp[P.q + P.qd + qd];
+    cold[(qd * 3 + 2) * NB + c] = xj * hyp[P.q + P.qd + qd] * PI_SQRT2;      // (the scaling of k_precompute's staged factors)
   }
   if (threadIdx.x < P.q) wl[threadIdx.x] = hyp[threadIdx.x];
   __syncthreads();

@@ -806,7 +806,9 @@ def test_config3_per_gpu_shard_of_64(dev):
     out24, ll24 = sharded_batch_step(shard, B, 24)
     torch.cuda.synchronize()
     assert ll.shape == (B,) and int(out["info"].abs().max()) == 0 and bool(torch.isfinite(ll).all())
-    assert torch.allclose(ll, ll24, rtol=0, atol=1e-12) and torch.allclose(out["g_mu"], out24["g_mu"], rtol=1e-10, atol=1e-14)
+    # (the value does not depend on the launch set; the gradient sums of a set of 64 and more are formed per whole tile, those
+    #  of the sets of 24 per k-split work item: equal to rounding)
+    assert torch.equal(ll, ll24) and _rel(out["g_mu"].reshape(-1), out24["g_mu"].reshape(-1)) < 1e-10
     cpu = {k: v.cpu() for k, v in shard.items()}
     for i in (0, B - 1):
         val, gr = orc.mll_value_grad_closed_form(cpu["x"][i], cpu["y"][i], cpu["mean"][i], cpu["noise"][i], cpu["w"][i], cpu["mu"][i], cpu["v"][i])

@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel statistics of one evalloop command: tools/lab/st.sh <tag> <evalloop args>
+# kernel statistics of one evalloop command: tools/lab/st.sh <tag> <evalloop args>   (PGM_LIBDIR=tools/variants/<name>: that build)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export LD_LIBRARY_PATH=$R/pgmuvi_amd:$LD_LIBRARY_PATH
+export LD_LIBRARY_PATH=$R/${PGM_LIBDIR:-pgmuvi_amd}:$LD_LIBRARY_PATH
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/st_$tag -o s -- $R/tools/evalloop "$@" > $R/gpurun_out/st_$tag.log 2>&1 || exit 1
 f=$(find $R/gpurun_out/st_$tag -name '*kernel_stats.csv' | head -1)
 tail -3 $R/gpurun_out/st_$tag.log
