@@ -72,7 +72,9 @@ template <class C>
 __device__ __forceinline__ WavePos wave_pos() {
   WavePos p;
   p.lane = threadIdx.x & 63;
-  p.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform: the sub-tile's place stays in scalar registers)
+  // (wave-uniform: the sub-tile's place stays in scalar registers.  Modulo the configuration's wavefronts: a workgroup of 16
+  //  wavefronts may run four 4-wavefront tiles of a barrier-free configuration side by side, k_trsm16)
+  p.wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) % (C::NT / 64);
   p.m0 = (p.wave / C::WAVES_N) * C::WM;
   p.n0 = (p.wave % C::WAVES_N) * C::WN;
   return p;

@@ -104,6 +104,7 @@ struct pgm_ws {
   int inleft;            // batches: left-looking inside a panel (run_sweep)
   int strips_min;        // batches: k_trsm_strips from this many block rows x light curves on
   int strips;            // batches: row solve by k_trsm_strips
+  int trsm16;            // fused sweep: the chain's row solve by k_trsm16 (16 wavefronts, one memory round trip)
   int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
   int build_beside;      // one light curve, 1-D spectral mixture: build the matrix below block row 0 beside diagonal block 0 (PGM_BUILD_BESIDE=0: off)

@@ -1013,6 +1013,193 @@ __global__ __launch_bounds__(CfgTrsmChain::NT, 2) void k_trsm(PgmDev P, int k, i
 }
 
 // ---------------------------------------------------------------------------
+// The chain's row solve, round 4: the same launch -- look-ahead workgroups, slab workgroups, update sub-tiles and early
+// inverse-pass products in the grid's tail -- on workgroups of 16 wavefronts that go through memory ONCE.
+// k_trsm stages U_kk^-1 and its slab through LDS in eight 16-row chunks, one barrier and an LDS round trip per chunk, the
+// second half of the chunks requested when the first has been consumed: stamps (s_memtime) put a look-ahead workgroup at
+// 5.5 us for the solve + 1.8 us for its 32-step product and a slab workgroup at 6.5 us, of which the MFMA work is 0.4 us --
+// the rest is two memory round trips and eight chunk latencies in sequence, once per block row on the chain.
+// Here every global load of the workgroup is issued in its first instructions: the upper triangle of U_kk^-1 (72 KB, all threads
+// together, to LDS) and each wavefront's B fragments straight into registers (wavefront (rb, h) owns the 16 x 16 block of rows
+// 16 rb .. of column half h and needs the rows p < 16 (rb + 1) only: U_kk^-1 is upper triangular) -- one round trip; then one
+// barrier, and every wavefront runs its own chain of 4 (rb + 1) MFMAs with A fragments from LDS.  The MFMAs that are left out
+// would add exact zeros and the others run in k order from a zero accumulator, the forward-substitution sums are formed from
+// an LDS image of the solved slab in the slab kernel's order, and the look-ahead block takes its 32 k-steps in order from -C:
+// same bits as k_trsm (PGM_TRSM16=0; tests compare).
+// ---------------------------------------------------------------------------
+using CfgSmall = TileCfg<64, 64, 32, 32, 8, 256, KB, true>;   // 64x64 tiles on 4 wavefronts, direct form (also: deep updates with few tiles, quarter tiles of the inverse pass)
+constexpr int T16_THREADS = 1024;
+// LDS of a workgroup: U_kk^-1 as eight column panels -- panel rb holds the rows p < 16 (rb + 1) of the columns 16 rb .. 16 rb + 15,
+// all a wavefront of row block rb ever reads, 72 KB for the upper triangle instead of 147 KB for the padded square -- then per
+// 16-column half of the slab an image of the unsolved and one of the solved values, [row][16].  (Pitch 16 doubles: the rows
+// 4 kk + g, g = 0 .. 3, of one fragment read fall on disjoint bank halves.)
+constexpr int T16_PANEL = 16 * NB / 2 * 9;                     // sum over rb of 16 (rb + 1) rows x 16 columns
+constexpr int T16_HALF = NB * 16;
+constexpr int T16_LDS = T16_PANEL + 4 * T16_HALF;              // 139 KB
+static_assert(T16_LDS <= NB * PM, "as large as the diagonal block's image at most");
+__device__ __forceinline__ int t16_panel(int rb) { return 128 * rb * (rb + 1); }     // first double of panel rb
+// the tail's 64x64 sub-tiles: two side by side on the workgroup's 16 wavefronts, eight each (a 32x16 block per wavefront) --
+// the granularity of k_trsm's tail, two sub-tiles per CU at a time -- in the direct form of the multiply loop (no barrier,
+// no LDS: the two halves of the workgroup never meet)
+using CfgTail16 = TileCfg<64, 64, 32, 16, 8, 512, KB, true>;
+// wavefront <-> (row block, column half): row blocks rb and 7 - rb on one SIMD -- a wavefront w runs on SIMD w % 4 --, so that
+// every SIMD has 4 (rb + 1) + 4 (8 - rb) = 36 MFMAs per half (with rb = w % 8 SIMD 3 had 48 and the launch waited for it)
+__device__ __forceinline__ int t16_rb(int wave) { return (wave & 4) ? 7 - (wave & 3) : (wave & 3); }
+__device__ __forceinline__ int t16_wave(int rb, int h) { return (rb < 4 ? rb : 11 - rb) + 8 * h; }
+
+// U = Uinv_kk^T C for the 128 x 32 slab at Cs (pitch ldc; its right half hsplit doubles further along: two 16-column slabs of
+// the look-ahead copy, or 16 for one slab of 32): every wavefront (rb, h) leaves its 16 x 16 block in the solved image of its
+// half (lds + T16_PANEL + (2 + h) T16_HALF), in place when `store`, and then raises done[wave].  `halves` = 1: only the left 16
+// columns (wavefronts 8 .. 15 idle).  No barrier after the one that publishes the operands: whoever needs solved blocks waits
+// for their flags (the look-ahead's product, which walks down the rows as they are finished) or for the workgroup's next
+// barrier (the slab's forward substitution).  Compact code on purpose: a workgroup runs it once, behind a diagonal-block
+// launch that has evicted it from the instruction cache -- the first version, with the 32 k-steps and the 32 fragment loads of a
+// wavefront unrolled and guarded one by one, spent more time fetching instructions than multiplying (3.1 us for a 32-step chain).
+__device__ __forceinline__ void solve_slab16(const double* __restrict__ Uinv, double* __restrict__ Cs, int64_t ldc, int hsplit,
+                                             int halves, bool store, double* lds, volatile int* done) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int rb = t16_rb(wave), h = wave >> 3;
+  const int g = lane >> 4, n = lane & 15;
+  double* pan = lds;
+  double* Bs = lds + T16_PANEL;                               // unsolved halves, then the solved ones
+  {  // every global load of the workgroup, at once: the slab (two 16-byte pieces per thread), then the panels of U_kk^-1
+    v2d bt[2], ut[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = t + u * T16_THREADS, row = e >> 4, c2 = (e & 15) * 2;
+      if (c2 < 16 * halves) bt[u] = *reinterpret_cast<const v2d*>(Cs + (int64_t)row * ldc + (c2 < 16 ? c2 : hsplit + c2 - 16));
+    }
+    const int prow = t >> 3, pc2 = (t & 7) * 2;               // panel q: thread t < 128 (q + 1) takes piece (row t / 8, columns 2 (t % 8) ..)
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (t < 128 * (q + 1)) ut[q] = *reinterpret_cast<const v2d*>(Uinv + prow * NB + 16 * q + pc2);
+    if (t < 16) done[t] = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = t + u * T16_THREADS, row = e >> 4, c2 = (e & 15) * 2;
+      if (c2 < 16 * halves) *reinterpret_cast<v2d*>(Bs + (c2 >> 4) * T16_HALF + row * 16 + (c2 & 15)) = bt[u];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (t < 128 * (q + 1)) *reinterpret_cast<v2d*>(pan + t16_panel(q) + prow * 16 + pc2) = ut[q];
+  }
+  __syncthreads();
+  if (h < halves) {                                           // (uniform) 4 (rb + 1) k-steps in order, fragments one group of four ahead
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = pan + t16_panel(rb) + g * 16 + n;
+    const double* pb = Bs + h * T16_HALF + g * 16 + n;
+    double a[4], bq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = pa[u * 64]; bq[u] = pb[u * 64]; }
+#pragma clang loop unroll(disable)
+    for (int gq = 0; gq <= rb; ++gq) {
+      double an[4], bn[4];
+      const int nx = (gq < rb) ? gq + 1 : gq;                  // (the last group reads its own fragments again: no branch in the loop)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { an[u] = pa[(4 * nx + u) * 64]; bn[u] = pb[(4 * nx + u) * 64]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = an[u]; bq[u] = bn[u]; }
+    }
+    double* Us = Bs + (2 + h) * T16_HALF;
+    double* Ch = Cs + (h ? hsplit : 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * rb + g + 4 * r;
+      Us[row * 16 + n] = acc[r];
+      if (store) Ch[(int64_t)row * ldc + n] = acc[r];          // (in place: every thread's loads of the slab were over before the barrier)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the block is in LDS: raise the flag
+    if (lane == 0) done[wave] = 1;
+  }
+}
+
+__global__ __launch_bounds__(T16_THREADS) void k_trsm16(PgmDev P, int k, int nslabs, int k_end, int r_from, FillPlan plan, int nlook, int nextra, int task_lo) {
+  __shared__ __attribute__((aligned(16))) double pan[T16_LDS];
+  __shared__ double zs[NB];
+  __shared__ double red[8][16];
+  __shared__ int done[16];
+  double* Us = pan + T16_PANEL + 2 * T16_HALF;                // solved image of half h at Us + h T16_HALF: [row][16]
+  const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+  if ((int)blockIdx.x < nlook) {
+    // look-ahead: the 16 x 16 block (s1, s2) of the next diagonal tile, A_{k+1,k+1} -= U[:, s1]^T U[:, s2], from this
+    // workgroup's own solve of the two slabs (the copy of the unsolved tile in P.crit).  The product's 32 k-steps run in order
+    // from -C on wavefront 0 -- whose own row block, the first, is solved after four MFMAs -- and follow the other wavefronts
+    // down the rows: k-step kk needs row block kk / 4, which is finished 4 (kk / 4 + 1) MFMAs into the solve.
+    int s1, s2;
+    tri_decode((int)blockIdx.x, s1, s2);
+    double* Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + s1 * LOOK_SLAB + g) * P.ld + (k + 1) * NB + s2 * LOOK_SLAB + n;
+    v4d d = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {                                          // (final since the launch before: its round trip rides with the others)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r] = Cd[(int64_t)4 * r * P.ld];
+    }
+    const int halves = (s1 == s2) ? 1 : 2;
+    solve_slab16(Uinv, P.crit + (int64_t)b * NB * NB + s1 * LOOK_SLAB, NB, (s2 - s1) * LOOK_SLAB, halves, false, pan, done);
+    if (wave == 0) {
+      const double* u1 = Us + g * 16 + n;
+      const double* u2 = Us + (halves - 1) * T16_HALF + g * 16 + n;
+      d = -d;
+#pragma clang loop unroll(disable)
+      for (int rbn = 0; rbn < NB / 16; ++rbn) {
+        // (bounded: a flag that never comes -- it cannot, the wavefronts of a workgroup are resident together -- ends in a wrong
+        //  block and a failed factorisation, not in a hang)
+        for (int spin = 0; spin < (1 << 22) && (done[t16_wave(rbn, 0)] == 0 || done[t16_wave(rbn, halves - 1)] == 0); ++spin) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[(4 * rbn + u) * 64], u2[(4 * rbn + u) * 64], d, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cd[(int64_t)4 * r * P.ld] = -d[r];
+    }
+    return;
+  }
+  const int bx0 = (int)blockIdx.x - nlook;
+  // (`nextra` counts pairs of sub-tiles here: a workgroup takes two, eight wavefronts each)
+  if (bx0 >= nslabs + nextra) {                                  // early inverse-pass products on CUs the launch leaves idle
+    const int e = 2 * (bx0 - nslabs - nextra) + (wave >> 3);
+    early_inverse_tile<CfgTail16>(P, pan, P.tasks[task_lo + e / 4], e % 4);
+    return;
+  }
+  if (bx0 >= nslabs) { plan_tile<CfgTail16>(P, pan, plan, k_end, r_from, 2 * (bx0 - nslabs) + (wave >> 3)); return; }
+  // one 32-column slab of block (k, jb): solved in place, then its share of the forward substitution / alpha update
+  const int slab = bx0 % TRSM_SLABS;
+  int jb = bx0 / TRSM_SLABS;
+  if (P.need_grad) { if (jb >= k) jb += 1; } else { jb += k + 1; }
+  if (t < NB) zs[t] = P.z[b * P.sVec + k * NB + t];
+  double* Cb = P.A + b * P.sA + (int64_t)k * NB * P.ld + jb * NB + slab * CfgTrsmChain::BN;
+  solve_slab16(Uinv, Cb, P.ld, 16, 2, true, pan, done);
+  __syncthreads();                                            // every block of the slab is solved
+  if (wave < 8) {                                             // the sums of trsm_slab, in its order: wavefront (mw, nw) = 32 rows x 16 columns
+    const int mw = wave >> 1, nw = wave & 1;
+    double sp = 0.0;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * mw + 16 * ti + g + 4 * r;
+        sp = __builtin_fma(Us[nw * T16_HALF + row * 16 + n], zs[row], sp);
+      }
+    sp += __shfl_xor(sp, 16, 64);
+    sp += __shfl_xor(sp, 32, 64);
+    if (lane < 16) red[wave][lane] = sp;
+  }
+  __syncthreads();
+  if (t < CfgTrsmChain::BN) {
+    const int nw = t / 16, cc = t % 16;
+    double tot = 0.0;
+#pragma unroll
+    for (int mw = 0; mw < 4; ++mw) tot += red[mw * 2 + nw][cc];
+    const int64_t gi = b * P.sVec + jb * NB + slab * CfgTrsmChain::BN + t;
+    if (jb > k) P.r[gi] -= tot; else P.alpha[gi] += tot;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The row solve of batches (panel / left-looking sweeps, where the launch is throughput work, not a link of a latency chain).
 // The slab kernel above runs one 128-deep product per workgroup behind a fresh copy of U_kk^-1: 160 KB fetched for 2 us of
 // MFMA, the launch bound by prologues (64 x N=2048: 97 us per block row at a quarter of the matrix pipe).  Here a workgroup
@@ -1187,7 +1374,6 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 using CfgBigLds = TileCfg<128, 128, 64, 64, 2>;
 struct CfgBig : TileCfg<128, 128, 64, 64, 4, 256, KB, true> { static constexpr int LDS_DOUBLES = CfgBigLds::LDS_DOUBLES; };
 using CfgUpd = CfgBig;                                       // (8 wavefronts per 128x128 tile: measured in round 2, -0.7 %, not kept)
-using CfgSmall = TileCfg<64, 64, 32, 32, 8, 256, KB, true>;
 using CfgSub = CfgSmall;                                     // quarter tiles of the inverse/gradient pass of short light curves
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
