@@ -68,6 +68,7 @@ struct PgmDev {
   int ainv_from_tiles; // k-blocks per work item (0 = off): diag(A^-1) is taken from the accumulators of the (j, j) tiles' work items
                       //    in the inverse/gradient launch (item number s of the tile -> dpart row s) and the separate column-sum
                       //    pass over V is skipped
+  int prebuilt;       // 1: the kernel matrix was built in front of the graph, by k_prebuild together with the per-point factors (short light curves)
   int build_beside;   // 1: k_build builds block row 0 only, the rest of the matrix is built by the spare workgroups of diagonal block 0's launch
   int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups)
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
@@ -104,6 +105,7 @@ struct pgm_ws {
   int inleft;            // batches: left-looking inside a panel (run_sweep)
   int strips_min;        // batches: k_trsm_strips from this many block rows x light curves on
   int strips;            // batches: row solve by k_trsm_strips
+  int prebuild;          // short light curves: per-point factors and kernel matrix in one launch (k_prebuild)
   int trsm16;            // fused sweep: the chain's row solve by k_trsm16 (16 wavefronts, one memory round trip)
   int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)

@@ -180,7 +180,7 @@ constexpr int BUILD_SPLIT_1D = 4, BUILD_SPLIT_SMALL = 16;
 // Shared by k_build and by the build workers beside diagonal block 0 (k_diag).
 template <int SPLIT>
 __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* rowd, const double* cold, const double* wl,
-                                              int b, int ib, int jb, int part, int tid) {
+                                              int b, int ib, int jb, int part, int tid, const double* dadd = nullptr) {
   double* A = P.A + b * P.sA;
   const int n = pts(P, b);
   const int c2 = (tid & 63) * 2, rg = tid >> 6;
@@ -217,12 +217,79 @@ __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* row
       for (int u = 0; u < 2; ++u) {
         const int gj = jb * NB + c2 + u;
         double val = acc[rr][u];
-        if (gi < n && gj < n) { if (gi == gj) val += P.diagadd[b * P.sVec + gi]; }
+        if (gi < n && gj < n) { if (gi == gj) val += dadd ? dadd[gi - ib * NB] : P.diagadd[b * P.sVec + gi]; }
         else val = (gi == gj) ? 1.0 : 0.0;
         out[u] = val;
       }
       *reinterpret_cast<v2d*>(A + (int64_t)gi * P.ld + jb * NB + c2) = out;
     }
+}
+
+// Short light curves (one of at most 32 tiles, 1-D): per-point factors and kernel matrix in ONE launch in front of the graph --
+// an evaluation of N = 89 points is five dependent launches of which the first two do microseconds of work.  A workgroup
+// computes the factors of its tile's 128 rows and 128 columns itself, straight from the caller's arrays into LDS (4 sincospi per
+// thread at Q = 4) and builds its sixteenth of the tile from them (build_part_1d, the code of k_build); the workgroups of the
+// diagonal tiles also leave their block row's factors, residual and diagonal addend in the workspace, where the later
+// kernels expect what k_precompute writes -- the same expressions, hence the same bits.
+__global__ __launch_bounds__(256) void k_prebuild(PgmDev P) {
+  constexpr int SPLIT = BUILD_SPLIT_SMALL;
+  const int b = blockIdx.z, t = threadIdx.x;
+  const int part = blockIdx.x % SPLIT;
+  int ib, jb;
+  tri_decode(blockIdx.x / SPLIT, ib, jb);
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD + NB doubles
+  double* rowd = sm;
+  double* cold = sm + P.pre_slots * NB;
+  double* wl = cold + P.pre_slots * NB;
+  double* dloc = wl + PGM_MAX_QD;
+  const int cb = caller_slot(P, b), n = pts(P, b);
+  if (blockIdx.x == 0 && t == 0) P.info[b] = 0;
+  publish_output_pointers(P);
+  if (blockIdx.x == 0 && t < P.q + 2 * P.qd) {
+    double val;
+    if (t < P.q) val = P.w[(int64_t)cb * P.q + t];
+    else if (t < P.q + P.qd) val = P.mu[(int64_t)cb * P.qd + (t - P.q)];
+    else val = P.v[(int64_t)cb * P.qd + (t - P.q - P.qd)];
+    P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = val;
+  }
+  if (t < P.q) wl[t] = P.w[(int64_t)cb * P.q + t];
+  const bool writer = (ib == jb) && part == 0;                  // (uniform) this workgroup leaves block row ib's per-point values behind
+  double* pre = P.pre + b * P.sPre;
+  // points of the row block (side 0) and of the column block (side 1): one (point, side) per thread and round
+  for (int e = t; e < 2 * NB; e += 256) {
+    const int side = e >> 7, m = e & (NB - 1);
+    const int i = (side ? jb : ib) * NB + m;
+    const bool valid = i < n;
+    const int64_t ci = (int64_t)cb * P.cstride + i;
+    const double xi = valid ? P.x[ci] : 0.0;
+    double* fac = side ? cold : rowd;
+    fac[3 * P.q * NB + m] = xi;
+    for (int q = 0; q < P.q; ++q) {
+      const double mu = P.mu[(int64_t)cb * P.qd + q], v = P.v[(int64_t)cb * P.qd + q];
+      double sn, cs;
+      sincospi(2.0 * (xi * mu), &sn, &cs);
+      fac[(q * 3 + 0) * NB + m] = cs;
+      fac[(q * 3 + 1) * NB + m] = sn;
+      fac[(q * 3 + 2) * NB + m] = xi * v * PI_SQRT2;
+      if (writer && side == 0) {
+        pre[(int64_t)(q * 3 + 0) * P.np + i] = cs;
+        pre[(int64_t)(q * 3 + 1) * P.np + i] = sn;
+        pre[(int64_t)(q * 3 + 2) * P.np + i] = xi * v * PI_SQRT2;
+      }
+    }
+    if (side == 0) {
+      const double da = valid ? ((P.noise ? P.noise[ci] : 0.0) + P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0) + P.jitter) : 0.0;
+      dloc[m] = da;
+      if (writer) {
+        const int64_t vi = (int64_t)b * P.sVec + i;
+        pre[(int64_t)(3 * P.q) * P.np + i] = xi;
+        P.r[vi] = valid ? (P.y[ci] - P.mean[ci]) : 0.0;
+        P.diagadd[vi] = da;
+      }
+    }
+  }
+  __syncthreads();
+  build_part_1d<SPLIT>(P, rowd, cold, wl, b, ib, jb, part, t, dloc);
 }
 
 
@@ -1436,13 +1503,10 @@ __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
 // workgroup per tile would leave most CUs idle behind a 40 us gradient epilogue): four workgroups per work item, a 64x64
 // sub-tile each -- launch index 4 * item + sub-tile, one row of partial sums per workgroup (P.nitems counts workgroups).
 template <int D, int ORDER, class C>
-__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
+__device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, int b, int bx) {
   constexpr int SUB = NB / C::BM;                              // sub-tiles per side (1 or 2)
   static_assert(C::BM == C::BN && C::NT == NTHREADS && (SUB == 1 || SUB == 2), "whole tiles or quarter tiles");
-  int b = blockIdx.z, bx = blockIdx.x;
-  xcd_batch_remap(bx, b);
   if (P.info[b] != 0) return;
-  __shared__ __attribute__((aligned(16))) double lds[CfgBig::LDS_DOUBLES];
   // the diag(A^-1) items ride at the end of the grid (placed first they delay the long inverse tiles: +0.04 ms)
   if (bx >= P.nitems) { const int a = bx - P.nitems; ainv_diag_item(P, a % P.nb, a / P.nb, lds, b); return; }
   // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
@@ -1704,10 +1768,13 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
 // ---------------------------------------------------------------------------
 // mll = -(||z||^2 + log det A + n log 2 pi) / 2n ;  gradients from the partials.
 // ---------------------------------------------------------------------------
-constexpr int FIN_THREADS = 1024;
-__global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
-  const int b = blockIdx.z, t = threadIdx.x;
-  __shared__ double red[FIN_THREADS / 64];
+// One role of the finalise step on FIN_THREADS threads: role 0 = the scalars (mll, hyper-parameter gradients), role r >= 1 = the
+// per-point gradients of points (r - 1) FIN_THREADS ...  (Round 4, measured and not kept: for short light curves the LAST workgroup
+// of the inverse/gradient launch running these roles -- a ticket per workgroup behind a device-scope fence -- instead of a launch
+// of its own: N=89 0.052 -> 0.057 ms, N=1000 0.278 -> 0.315; the fences cost more than the launch, as with round 3's combine mode.)
+template <int FIN_THREADS>
+__device__ __forceinline__ void finalize_role(const PgmDev& P, int b, int role, double* red) {
+  const int t = threadIdx.x;
   const int bad = P.info[b];
   const int n = pts(P, b), cb = caller_slot(P, b);           // (ragged batches: this light curve's length and its place in the caller's arrays)
   // workgroup 0: the scalars (mll, hyper-parameter gradients); workgroups 1..: the per-point gradients
@@ -1723,10 +1790,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     c_gnoise = (double*)P.outp[4]; c_gmean = (double*)P.outp[5]; c_info = (int*)P.outp[6];
   }
   const int64_t cs = P.outp ? (int64_t)P.outp[8] : P.cstride;   // points per light curve slot in the caller's arrays
-  if (blockIdx.x > 0) {
+  if (role > 0) {
     if (!P.need_grad) return;
     const double half_n = 0.5 / (double)n;
-    const int i = ((int)blockIdx.x - 1) * FIN_THREADS + t;
+    const int i = (role - 1) * FIN_THREADS + t;
     if (bad) {
       if (i < n) {
         P.out_gmean[b * P.sVec + i] = qnan; P.out_gnoise[b * P.sVec + i] = qnan;
@@ -1806,6 +1873,20 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(PgmDev P) {
     // the last slot (sum of the diagonal of G) is only needed for a scalar noise: the
     // caller sums g_noise instead, so nothing to do here.
   }
+}
+
+constexpr int FIN_THREADS_K = 1024;
+__global__ __launch_bounds__(FIN_THREADS_K) void k_finalize(PgmDev P) {
+  __shared__ double red[FIN_THREADS_K / 64];
+  finalize_role<FIN_THREADS_K>(P, (int)blockIdx.z, (int)blockIdx.x, red);
+}
+
+template <int D, int ORDER, class C>
+__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
+  int b = blockIdx.z, bx = blockIdx.x;
+  xcd_batch_remap(bx, b);
+  __shared__ __attribute__((aligned(16))) double lds[CfgBig::LDS_DOUBLES];
+  lauum_grad_item<D, ORDER, C>(P, lds, b, bx);
 }
 
 // ---------------------------------------------------------------------------

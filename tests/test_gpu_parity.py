@@ -1437,7 +1437,7 @@ def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, 
     # ("slab8": the default schedule with the chain's row solve on the staged 8-wavefront kernel of rounds 1-3 instead of
     #  k_trsm16 -- every output bit for bit, the left-out MFMAs of the triangular solve add exact zeros)
     for name, env in (("default", {}), ("slab8", {"PGM_TRSM16": "0"}),
-                      ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0", "PGM_BUILD_BESIDE": "0", "PGM_EARLY_T": "0", "PGM_TRSM16": "0"})):
+                      ("plain", {"PGM_LOOKAHEAD": "99", "PGM_LAUUM_SUB": "0", "PGM_EARLY": "0", "PGM_LAZY": "0", "PGM_BUILD_BESIDE": "0", "PGM_EARLY_T": "0", "PGM_TRSM16": "0", "PGM_PREBUILD": "0"})):
         _hip.release_workspaces()
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
