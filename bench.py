@@ -311,6 +311,26 @@ def strong_scaling_run(h, total, n, steps, warmup, rank, world, dev, chunk=None,
     return res, prof, ws, nloc, (float(ll[0]) if total else None)
 
 
+def ragged_run(h, total, n_lo, n_hi, steps, warmup, rank, world, dev):
+    """A ``total``-light-curve batch with N ~ U{n_lo..n_hi} (what a real many-light-curve batch is: every pgmuvi ``Lightcurve``
+    has its own N): the light curves are dealt to the ranks by their N^3 (``balanced_assignment``), each rank runs its own
+    through the ragged entry point (launch sets that share a chain length), one all_gather of the log-likelihoods per step."""
+    from pgmuvi_amd.batch import make_ragged_shard, sharded_ragged_step
+    shard = make_ragged_shard(total, rank, world, n_lo, n_hi, device=dev)
+    step = lambda: sharded_ragged_step(shard, device=dev)
+    elapsed, (out, ll) = h.time(step, steps, warmup)
+    assert not shard["index"] or int(out["info"].abs().max()) == 0, "factorisation failed inside the timed region"
+    assert ll.numel() == total and bool(torch.isfinite(ll).all())
+    work = sum(float(n) ** 3 for n in shard["lengths"])
+    tfl = work * steps / elapsed / world / 1e12
+    sets = _hip.ragged_plan(shard["local_lengths"], max(1, min(default_chunk(n_hi), len(shard["local_lengths"]))))[1] if shard["index"] else []
+    return dict(total_batch=total, n_range=[n_lo, n_hi], steps=steps, warmup=warmup, evals_per_s=round(total * steps / elapsed, 3),
+                ms_per_step=round(elapsed / steps * 1e3, 4), light_curves_per_gpu=[shard["owner"].count(r) for r in range(world)],
+                launch_sets_rank0=len(sets), block_rows_of_the_sets_rank0=sets,
+                algorithmic_tflops_per_gpu=round(tfl, 3), algorithmic_frac_of_fp64_mfma_peak=round(tfl / FP64_MATRIX_PEAK_TFLOPS, 4),
+                sum_n3_over_padded=round(work / (total * float(n_hi) ** 3), 4), loglik_checksum=float(ll.sum()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,6 +494,9 @@ def main():
         for tag, total, nn, k, w in cases:
             ss[tag] = strong_scaling_run(h, total, nn, k, w, rank, world, dev, None, profile=False)[0]
             _hip.release_workspaces()
+        # the same 512 light curves as they come in practice: unequal lengths (ragged N)
+        ss["ragged_512_x_n1024_2048"] = ragged_run(h, 512, 1024, 2048, 3, 1, rank, world, dev)
+        _hip.release_workspaces()
         extra["strong_scaling"] = ss
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, cpu_val = cpu_baseline(n, args.cpu_reps)

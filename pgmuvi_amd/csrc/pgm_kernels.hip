@@ -1105,10 +1105,12 @@ constexpr int T16_HALF = NB * 16;
 constexpr int T16_LDS = T16_PANEL + 4 * T16_HALF;              // 139 KB
 static_assert(T16_LDS <= NB * PM, "as large as the diagonal block's image at most");
 __device__ __forceinline__ int t16_panel(int rb) { return 128 * rb * (rb + 1); }     // first double of panel rb
-// the tail's 64x64 sub-tiles: two side by side on the workgroup's 16 wavefronts, eight each (a 32x16 block per wavefront) --
-// the granularity of k_trsm's tail, two sub-tiles per CU at a time -- in the direct form of the multiply loop (no barrier,
-// no LDS: the two halves of the workgroup never meet)
-using CfgTail16 = TileCfg<64, 64, 32, 16, 8, 512, KB, true>;
+// the tail's 64x64 sub-tiles: one per workgroup on all 16 wavefronts (a 16x16 block each), staged through LDS in chunks of 32
+// rows -- as many 16-byte pieces per chunk as threads, no predicated loads.  (Measured against it: the direct form of the loop on
+// 16x16 blocks, and two sub-tiles side by side on eight wavefronts each -- both bound by the L1: a block that small re-fetches
+// its operands per wavefront; N=4096 1.87 -> 1.96 ms with them, 1.87 -> 1.85 with this one.)
+using CfgTail16 = TileCfg<64, 64, 16, 16, 2, 1024, 32>;
+static_assert(CfgTail16::LDS_DOUBLES <= T16_LDS, "staging inside the workgroup's LDS");
 // wavefront <-> (row block, column half): row blocks rb and 7 - rb on one SIMD -- a wavefront w runs on SIMD w % 4 --, so that
 // every SIMD has 4 (rb + 1) + 4 (8 - rb) = 36 MFMAs per half (with rb = w % 8 SIMD 3 had 48 and the launch waited for it)
 __device__ __forceinline__ int t16_rb(int wave) { return (wave & 4) ? 7 - (wave & 3) : (wave & 3); }
@@ -1226,13 +1228,12 @@ __global__ __launch_bounds__(T16_THREADS) void k_trsm16(PgmDev P, int k, int nsl
     return;
   }
   const int bx0 = (int)blockIdx.x - nlook;
-  // (`nextra` counts pairs of sub-tiles here: a workgroup takes two, eight wavefronts each)
   if (bx0 >= nslabs + nextra) {                                  // early inverse-pass products on CUs the launch leaves idle
-    const int e = 2 * (bx0 - nslabs - nextra) + (wave >> 3);
+    const int e = bx0 - nslabs - nextra;
     early_inverse_tile<CfgTail16>(P, pan, P.tasks[task_lo + e / 4], e % 4);
     return;
   }
-  if (bx0 >= nslabs) { plan_tile<CfgTail16>(P, pan, plan, k_end, r_from, 2 * (bx0 - nslabs) + (wave >> 3)); return; }
+  if (bx0 >= nslabs) { plan_tile<CfgTail16>(P, pan, plan, k_end, r_from, bx0 - nslabs); return; }
   // one 32-column slab of block (k, jb): solved in place, then its share of the forward substitution / alpha update
   const int slab = bx0 % TRSM_SLABS;
   int jb = bx0 / TRSM_SLABS;

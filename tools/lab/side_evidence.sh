@@ -12,4 +12,8 @@ python3 tools/trainbench.py > $o/trainbench.txt 2>&1
 python3 tools/configbench.py > $o/configbench.txt 2>&1
 python3 tools/batchbench.py > $o/batchbench.txt 2>&1
 python3 tools/densebench.py > $o/densebench.txt 2>&1
+python3 tools/raggedbench.py 512 1024 2048 3 > $o/raggedbench.txt 2>&1
+python3 tools/raggedbench.py 512 200 2300 3 >> $o/raggedbench.txt 2>&1
+( CHAINS=1 SAMPLES=10 WARMUP=20 python3 tools/nutsbench.py | head -2; CHAINS=8 SAMPLES=10 WARMUP=20 python3 tools/nutsbench.py | head -2 ) > $o/nutsbench_ticks.txt 2>&1
+[ -x tools/lab/ratelab ] && tools/lab/ratelab > $o/ratelab.txt 2>&1
 sha256sum pgmuvi_amd/libpgmuvi_hip.so > $o/lib_sha.txt
