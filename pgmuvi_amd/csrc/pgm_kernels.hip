@@ -175,7 +175,7 @@ __device__ __forceinline__ double sm_pair(const double* rowd, const double* cold
 // with the identity.  One workgroup per 128x128 tile; a wave stores one full row
 // (1 KiB) per instruction.
 // ---------------------------------------------------------------------------
-constexpr int BUILD_SPLIT_1D = 4, BUILD_SPLIT_SMALL = 16;
+constexpr int BUILD_SPLIT_1D = 4, BUILD_SPLIT_SMALL = 16, BUILD_SPLIT_BIG = 2;
 // 1-D kernel matrix: 1/SPLIT of the tile (ib, jb) -- rows part*NB/SPLIT ... -- by 256 threads (tid), factors staged in LDS.
 // Shared by k_build and by the build workers beside diagonal block 0 (k_diag).
 template <int SPLIT>
