@@ -225,7 +225,7 @@ __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* row
     }
 }
 
-// Short light curves (one of at most 32 tiles, 1-D): per-point factors and kernel matrix in ONE launch in front of the graph --
+// Short light curves (one of at most 55 tiles, 1-D): per-point factors and kernel matrix in ONE launch in front of the graph --
 // an evaluation of N = 89 points is five dependent launches of which the first two do microseconds of work.  A workgroup
 // computes the factors of its tile's 128 rows and 128 columns itself, straight from the caller's arrays into LDS (4 sincospi per
 // thread at Q = 4) and builds its sixteenth of the tile from them (build_part_1d, the code of k_build); the workgroups of the
