@@ -180,7 +180,7 @@ def sweep_roofline(prof, ws, n, nloc, steps):
         upd_launches += fused_launches + diag_launches + trsm_launches
     achieved = flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
     traffic, traffic_src = measured_traffic(bool(fused_launches), n, nloc)
-    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles incl. early inverse-pass products; k_trsm: row solve + update tiles; "
+    kname = ("factorisation sweep, all launches (k_diag: diagonal block + filler tiles incl. early inverse-pass products; k_trsm / k_trsm16: row solve + update tiles; "
              "k_update_rows): trailing-update + row-solve tile GEMM"
              if fused_launches else "trailing_update (k_update)") + ", v_mfma_f64_16x16x4_f64 TN"
     roofline = dict(bound="mfma", kernel=kname,
