@@ -217,9 +217,9 @@ def build_roofline(prof, n, nloc, q=4, beside=False):
     valu_floor_us = ntiles * nloc * NB * NB * q * BUILD_PAIR_INSTRS * VALU_F64_CYCLES / (256 * 4 * 64 * 2.4e3)
     kernel = "k_build (spectral-mixture kernel matrix, upper block triangle, one launch)"
     if beside:
-        kernel += ("; timed on a side workspace with PGM_BUILD_BESIDE=0, outside the timed region -- in the production path of one "
+        kernel += ("; timed on a side workspace with PGM_BUILD_BESIDE=0 PGM_PREBUILD=0, outside the timed region -- in the production path of one "
                    "light curve only block row 0 is a launch of its own, the other tiles are built by the spare workgroups of "
-                   "the first k_diag launch, hidden beside diagonal block 0")
+                   "the first k_diag launch, hidden beside diagonal block 0 (up to 55 tiles: factors and matrix by one launch, k_prebuild)")
     return dict(bound="hbm", kernel=kernel, achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
                 avg_launch_us=round(us, 2), bytes_per_launch=build_bytes,
                 exp_issue_floor_us=round(exp_floor_us, 2), frac_of_exp_issue_floor=round(exp_floor_us / us, 4) if us > 0 else None,
@@ -231,15 +231,17 @@ def build_roofline(prof, n, nloc, q=4, beside=False):
 def whole_build_profile(dev, data, n, reps=5):
     """Per-launch times of ``reps`` value-only evaluations of one light curve on a workspace created with
     PGM_BUILD_BESIDE=0 (the switch is read when a workspace is made): there the whole matrix is one k_build launch."""
-    prev = os.environ.get("PGM_BUILD_BESIDE")
+    prev = {k: os.environ.get(k) for k in ("PGM_BUILD_BESIDE", "PGM_PREBUILD")}
     os.environ["PGM_BUILD_BESIDE"] = "0"
+    os.environ["PGM_PREBUILD"] = "0"                        # (short light curves: factors and matrix otherwise come from one launch, k_prebuild)
     try:
         side = _hip.Workspace(dev, (n + NB - 1) // NB * NB, 4, 1, 1)
     finally:
-        if prev is None:
-            os.environ.pop("PGM_BUILD_BESIDE", None)
-        else:
-            os.environ["PGM_BUILD_BESIDE"] = prev
+        for k, v in prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     one = {k: v[0] for k, v in data.items()}
     f = lambda: _hip.mll_value_grad(one["x"], one["y"], one["mean"], one["noise"], None, one["w"], one["mu"], one["v"], 0, 0.0, False,
                                     workspace=side)
@@ -428,7 +430,9 @@ def main():
     ws.profile(False)
     roofline = sweep_roofline(prof, ws, n, B, args.steps)
     nbk = (n + NB - 1) // NB
-    beside = B == 1 and nbk * (nbk + 1) // 2 > 32 and os.environ.get("PGM_BUILD_BESIDE", "1") != "0"
+    # (one light curve never builds its matrix in one k_build launch in production: up to 55 tiles k_prebuild makes factors and
+    #  matrix together, beyond 32 tiles the spare workgroups of the first k_diag launch build all but block row 0)
+    beside = B == 1
     # the HBM-bound stage, whole: where the production path hides most of the build inside the first k_diag launch it is
     # timed once on a side workspace that builds the matrix in one launch (outside the timed region)
     roofline_build = build_roofline(whole_build_profile(dev, data, n) if beside else prof, n, 1 if beside else B, beside=beside)

@@ -1727,6 +1727,27 @@ def test_bench_collective_path_on_rccl(dev):
         assert out["roofline_build"]["frac"] > 0 and out["roofline_build"]["exp_issue_floor_us"] > 0
 
 
+def test_ragged_step_gathers_over_rccl(dev):
+    """The ragged batch's collective on RCCL (a one-rank "nccl" group on this one-GPU box): ``make_ragged_shard`` +
+    ``sharded_ragged_step`` -- evaluation through the ragged entry point, then ``gather_by_owner``'s all_gather of padded buffers --
+    returns the batch's log-likelihoods in the batch's own order, equal to the local evaluation."""
+    import datetime
+    import torch.distributed as dist
+    from pgmuvi_amd.batch import make_ragged_shard, sharded_ragged_step
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29641", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+    try:
+        shard = make_ragged_shard(12, 0, 1, 100, 700, device=dev)
+        out, ll = sharded_ragged_step(shard, device=dev)
+        torch.cuda.synchronize()
+        assert ll.shape == (12,) and ll.is_cuda and torch.equal(ll, out["mll"]) and int(out["info"].abs().max()) == 0
+        c, n = shard["curves"][5], shard["lengths"][5]
+        single = _hip_eval(dev, c["x"].reshape(n, 1), c["y"], c["mean"], c["noise"], c["w"], c["mu"].reshape(4, 1), c["v"].reshape(4, 1))
+        assert float(single["mll"]) == float(ll[5])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_performance_guards(dev):
     """Timing guards (1.5 x what one MI355X measures, best of three) for the shapes a change to one schedule can break without
     any parity test noticing: one N=4096 light curve, shards of 2048-point curves, thousands of short curves per call, config 4's size."""
