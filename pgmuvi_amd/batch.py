@@ -87,24 +87,80 @@ def pad_curves(curves: Sequence[Dict[str, torch.Tensor]], device=None) -> Tuple[
     return out, lengths
 
 
+_twin_workspaces: Dict[tuple, list] = {}
+
+
+def _two_streams(padded, lengths, dim_order, need_grad, max_batch, streams):
+    """Two launch sets at a time: a set of a few dozen light curves leaves CUs idle in the latency-bound links of its sweep (its
+    diagonal blocks are one workgroup per member), which another set's updates can use.  The sets (``pgm_ragged_plan``) are
+    dealt alternately to two ragged calls, each on a stream and a workspace of its own (512 x N ~ U{1024..2048}: 58.2 -> 54.1 ms
+    per pass on one MI355X; the values do not depend on it).  None when there is nothing to overlap (``streams`` None: from
+    four sets on)."""
+    set_of, nbs = _hip.ragged_plan(lengths, max_batch)
+    if len(nbs) < (2 if streams == 2 else 4):
+        return None
+    dev = padded["y"].device
+    halves = [[i for i, s_ in enumerate(set_of) if s_ % 2 == p] for p in (0, 1)]
+    B, S = padded["y"].shape
+    q, d = padded["w"].shape[-1], padded["x"].shape[-1]
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), (max(lengths) + 127) // 128 * 128, q, d,
+           max(len(h) for h in halves))
+    wss = _twin_workspaces.get(key)
+    if wss is None:
+        _twin_workspaces.clear()                                 # (one pair at a time: the previous batch shape's buffers go)
+        wss = [_hip.Workspace(dev, key[1], q, d, min(key[4], max_batch)) for _ in range(2)]
+        _twin_workspaces[key] = wss + [[torch.cuda.Stream(device=dev) for _ in range(2)]]
+    wss, sts = _twin_workspaces[key][:2], _twin_workspaces[key][2]
+    cur = torch.cuda.current_stream(dev)
+    parts = []
+    for idx, ws, st in zip(halves, wss, sts):
+        ix = torch.as_tensor(idx, device=dev)
+        sub = {k: v.index_select(0, ix) for k, v in padded.items() if torch.is_tensor(v)}
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            parts.append((ix, _hip.mll_value_grad_ragged(sub["x"], sub["y"], sub["mean"], sub.get("noise"), sub.get("noise_scalar"),
+                                                       [lengths[i] for i in idx], sub["w"], sub["mu"], sub["v"], dim_order, 0.0,
+                                                       need_grad, workspace=ws)))
+    for st in sts:
+        cur.wait_stream(st)
+    keys = ["mll", "info"] + (["g_w", "g_mu", "g_v", "g_noise", "g_mean"] if need_grad else [])
+    out = {}
+    for k in keys:
+        first = parts[0][1][k]
+        full = torch.zeros((B,) + tuple(first.shape[1:]), dtype=first.dtype, device=dev)
+        for ix, o in parts:
+            full.index_copy_(0, ix, o[k])
+        out[k] = full
+    out["_keep"] = parts                                         # (the halves' inputs stay alive until the results have been used)
+    return out
+
+
 def evaluate_ragged(curves=None, padded: Optional[Dict[str, torch.Tensor]] = None, lengths: Optional[Sequence[int]] = None,
-                    dim_order=0, need_grad=True, chunk: Optional[int] = None, device=None, _compute=None) -> Dict[str, object]:
+                    dim_order=0, need_grad=True, chunk: Optional[int] = None, device=None, streams: Optional[int] = None,
+                    _compute=None) -> Dict[str, object]:
     """MLL (+ gradients) of light curves of DIFFERENT lengths on the local device -- what a real many-light-curve batch is
     (every pgmuvi ``Lightcurve`` has its own N, ``/root/reference/pgmuvi/lightcurve.py:1724-1733, 2150-2181``).
 
     Either ``curves`` (a list of per-curve dictionaries, see :func:`pad_curves`) or the ``padded`` arrays with ``lengths``.
     The library sorts the light curves by their block-row count -- i.e. by N^3, SURVEY.md section 8e -- and runs them in
     launch sets that share a chain length (``pgm_mll_value_grad_ragged_f64``); ``chunk`` bounds the light curves per launch
-    set (workspace memory, default :func:`default_chunk` of the longest).  Returns mll (B,), info (B,), g_w (B,Q), g_mu,
+    set (workspace memory, default :func:`default_chunk` of the longest); ``streams``: 1 = the sets one after the other on the
+    current stream, 2 = alternately on two streams and two workspaces, None = two from four sets on.  Returns mll (B,), info (B,), g_w (B,Q), g_mu,
     g_v (B,Q,d) and g_noise / g_mean as lists of B vectors of each light curve's own length."""
     if padded is None:
         padded, lengths = pad_curves(curves, device=device)
     lengths = [int(n) for n in lengths]
     compute = _compute or _hip.mll_value_grad_ragged
     B = len(lengths)
+    if B != padded["y"].shape[0] or min(lengths) < 1 or max(lengths) > padded["y"].shape[1]:
+        raise ValueError(f"evaluate_ragged: {padded['y'].shape[0]} lengths in [1, {padded['y'].shape[1]}] expected")
     chunk = chunk or default_chunk(max(lengths), device=padded["y"].device)
-    o = compute(padded["x"], padded["y"], padded["mean"], padded.get("noise"), padded.get("noise_scalar"), lengths,
-                padded["w"], padded["mu"], padded["v"], dim_order, 0.0, need_grad, max_batch=max(1, min(chunk, B)))
+    o = None
+    if _compute is None and streams != 1 and padded["y"].is_cuda:
+        o = _two_streams(padded, lengths, dim_order, need_grad, max(1, min(chunk, B)), streams)
+    if o is None:
+        o = compute(padded["x"], padded["y"], padded["mean"], padded.get("noise"), padded.get("noise_scalar"), lengths,
+                    padded["w"], padded["mu"], padded["v"], dim_order, 0.0, need_grad, max_batch=max(1, min(chunk, B)))
     out = {"mll": o["mll"], "info": o["info"], "lengths": lengths}
     if need_grad:
         out.update(g_w=o["g_w"], g_mu=o["g_mu"], g_v=o["g_v"])

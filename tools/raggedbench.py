@@ -36,8 +36,12 @@ def timed(f):
     return best * 1e3
 
 
+rag1 = timed(lambda: evaluate_ragged(padded=padded, lengths=lens, chunk=chunk, streams=1))
 rag = timed(lambda: evaluate_ragged(padded=padded, lengths=lens, chunk=chunk))
 out = evaluate_ragged(padded=padded, lengths=lens, chunk=chunk)
+out1 = evaluate_ragged(padded=padded, lengths=lens, chunk=chunk, streams=1)
+torch.cuda.synchronize()
+assert torch.equal(out["mll"], out1["mll"])
 # the same light curves padded to n_hi points each (what the equal-length call forces on a caller): the cfg-3 recipe at n_hi
 xs, ys, ms, ns, ws, mus, vs = [], [], [], [], [], [], []
 for i in range(min(B, 64)):
@@ -50,7 +54,9 @@ st = lambda L: torch.stack(L).repeat(rep, *([1] * L[0].dim()))[:B].to(dev).conti
 x, y, m, nz, w, mu, v = st(xs), st(ys), st(ms), st(ns), st(ws), st(mus), st(vs)
 eq = timed(lambda: evaluate_batch(x, y, m, nz, w, mu, v, chunk=chunk))
 work = sum(float(n) ** 3 for n in lengths)
-print(f"ragged entry point: {rag:.2f} ms per pass = {B / rag * 1e3:.0f} evaluations/s, {work / rag * 1e-9:.1f} TFLOP/s on the light curves' own N^3 "
+print(f"ragged entry point, the sets one after the other on one stream: {rag1:.2f} ms per pass = {B / rag1 * 1e3:.0f} evaluations/s "
+      f"({work / rag1 * 1e-9 / 78.6:.3f} of the fp64 MFMA peak on the light curves' own N^3)")
+print(f"ragged entry point, two launch sets at a time (two streams, two workspaces: evaluate_ragged's default): {rag:.2f} ms per pass = {B / rag * 1e3:.0f} evaluations/s, {work / rag * 1e-9:.1f} TFLOP/s on the light curves' own N^3 "
       f"({work / rag * 1e-9 / 78.6:.3f} of the fp64 MFMA peak); info max {int(out['info'].abs().max())}")
 print(f"padded to N={n_hi}, equal-length call: {eq:.2f} ms per pass = {B / eq * 1e3:.0f} evaluations/s   (ragged / padded time: {rag / eq:.3f}; "
       f"sum N^3 / B n_hi^3 = {work / (B * float(n_hi) ** 3):.3f})")
