@@ -1,7 +1,7 @@
 """Two sub-batches on two streams (each with a workspace of its own) against one launch set: does the second stream fill the
 CUs the diagonal-block launches and the launch tails of the first leave idle?   python tools/streambench.py [n] [B]"""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '.')
 from pgmuvi_amd import _hip
 from pgmuvi_amd.batch import make_shard
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
