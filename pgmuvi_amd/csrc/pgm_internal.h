@@ -12,6 +12,21 @@ constexpr int CRIT_MAX = 48;      // light curves per call the fused sweep is ev
 // A composed stationary kernel as a sum of products of leaf kernels (pgm_generic.inc); mirrors pgm_kernel_program of the
 // C ABI.  Travels by value inside PgmDev (kernel arguments: decoding it touches no memory).
 constexpr int KP_MAXL = 6, KP_MAXT = 4, KP_MAXP = 12;
+// Trimmed ragged launch sets (PgmDev::trim): the members are sorted by block rows, longest first, so the light curves of one
+// block-row count ("class") are neighbours: class c = members z0[c] .. z0[c+1]-1, nb[c] block rows, x[c] workgroups each in this
+// launch -- exactly the tiles such a member has.  The trailing update and the inverse/gradient pass run as ONE 1-D grid per
+// launch instead of a (tiles of the longest) x (members) box whose workgroups leave at once where a member has no such tile
+// (the dispatcher still spends ~20 ns on each).  The dispatcher deals workgroups round-robin to the 8 XCDs; XCD g (workgroups
+// w = 8 s + g) works through the members m = g, g + 8, g + 16 ... one after the other, all workgroups of one before the next --
+// the placement of xcd_batch_remap, whatever the class sizes.  Travels as a kernel argument (decoding touches no memory beyond
+// the kernarg segment).  n = 0: the box.
+constexpr int RAG_MAX_CLASS = 64;
+struct RagClasses {
+  int n;
+  int x[RAG_MAX_CLASS];
+  unsigned short z0[RAG_MAX_CLASS + 1];
+  unsigned char nb[RAG_MAX_CLASS];
+};
 struct KProg {
   int nleaf, nterm, nparam;
   unsigned char kind[KP_MAXL];       // leaf kind (KLeaf)
@@ -53,6 +68,11 @@ struct PgmDev {
   // np / nb (the set's block-row count); the ones that are shorter end in identity padding, whole block rows of it if need be.
   const int* nvec;    // [batch] points of light curve b, or null: every light curve has P.n
   const int* cmap;    // [batch] the caller's index of workspace slot b (the sets are formed from a sorted order), or null: b
+  int trim_tri;       // 1 (trimmed sets of 64 members and more, whose inverse/gradient pass has one work item per tile): the work items
+                      //   of a member are the tiles of ITS block rows in triangular order, (i, j) <-> j (j + 1) / 2 + i, no table
+  int trim;           // 1 (ragged launch sets of the panel sweep): nothing is padded beyond a light curve's own block rows -- the
+                      //   workgroups of the build, the row solve, the updates and the inverse/gradient pass whose tile lies in a
+                      //   block row or column the light curve does not have leave at once, the others stop at its last block row
   int64_t cstride;    // points per light curve slot in the caller's arrays (= n unless ragged); k_finalize, replayed from a graph,
                       //   reads it from outp[8]
   unsigned long long* outp;   // [16] the caller's output pointers of THIS evaluation (mll, g_w, g_mu, g_v, g_noise, g_mean, info), left
@@ -105,6 +125,8 @@ struct pgm_ws {
   int inleft;            // batches: left-looking inside a panel (run_sweep)
   int strips_min;        // batches: k_trsm_strips from this many block rows x light curves on
   int strips;            // batches: row solve by k_trsm_strips
+  std::vector<int> rag_nb, rag_z0;   // the current trimmed set's classes: block rows, first member (+ one past the last), longest first
+  int ragged_trim;       // ragged batches: the launch sets of the panel sweep are merged, nothing padded beyond a light curve's own block rows (PgmDev::trim)
   int prebuild;          // short light curves: per-point factors and kernel matrix in one launch (k_prebuild)
   int trsm16;            // fused sweep: the chain's row solve by k_trsm16 (16 wavefronts, one memory round trip)
   int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on

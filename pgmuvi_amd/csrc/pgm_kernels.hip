@@ -82,6 +82,29 @@ __device__ __forceinline__ void xcd_batch_remap(int& x, int& b) {
 // points of light curve b / its index in the caller's arrays (ragged batches: pgm_internal.h)
 __device__ __forceinline__ int pts(const PgmDev& P, int b) { return P.nvec ? P.nvec[b] : P.n; }
 __device__ __forceinline__ int caller_slot(const PgmDev& P, int b) { return P.cmap ? P.cmap[b] : b; }
+// block rows light curve b really has (a trimmed ragged launch set, pgm_internal.h) -- otherwise the set's
+__device__ __forceinline__ int own_rows(const PgmDev& P, int b) { return P.trim ? (P.nvec[b] + NB - 1) / NB : P.nb; }
+// Workgroup -> (member b, index x among the member's own workgroups, the member's block rows) in the 1-D grid of a trimmed
+// ragged set (RagClasses, pgm_internal.h); false: a workgroup past the end of its XCD's list (the lists differ by a member
+// per class at most).
+__device__ __forceinline__ bool rag_decode(const RagClasses& rc, int& x, int& b, int& rows) {
+  const int g = (int)blockIdx.x & 7;
+  int s = (int)blockIdx.x >> 3;
+  for (int c = 0; c < rc.n; ++c) {
+    const int z0 = (int)rc.z0[c], z1 = (int)rc.z0[c + 1], X = rc.x[c];
+    const int first = z0 + ((g - z0) & 7);                       // the class's first member that is this XCD's
+    const int cnt = first < z1 ? (z1 - first + 7) >> 3 : 0;
+    if (s < cnt * X) {
+      const int i = s / X;
+      x = __builtin_amdgcn_readfirstlane(s - i * X);
+      b = __builtin_amdgcn_readfirstlane(first + 8 * i);
+      rows = __builtin_amdgcn_readfirstlane((int)rc.nb[c]);
+      return true;
+    }
+    s -= cnt * X;
+  }
+  return false;
+}
 
 __device__ __forceinline__ void publish_output_pointers(const PgmDev& P) {
   if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 64 && P.outp) {
@@ -303,6 +326,7 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   const int part = blockIdx.x % SPLIT;
   if (P.build_beside) { ib = 0; jb = blockIdx.x / SPLIT; }      // block row 0 only: the rest is built beside diagonal block 0 (k_diag)
   else tri_decode(blockIdx.x / SPLIT, ib, jb);
+  if (jb >= own_rows(P, b)) return;                              // (trimmed ragged set: a tile the light curve does not have; ib <= jb)
   extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD doubles
   double* rowd = sm;
   double* cold = sm + P.pre_slots * NB;
@@ -1285,6 +1309,11 @@ __global__ __launch_bounds__(STRIP_THREADS, 2) void k_trsm_strips(PgmDev P, int 
   __shared__ __attribute__((aligned(16))) double Ui[NB * PM];
   __shared__ double zs[NB];
   const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  {   // (trimmed ragged set: the light curve's own block columns only -- they are the first ones of the strip order)
+    const int own = own_rows(P, b);
+    if (k >= own) return;
+    nblocks -= P.nb - own;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
   {  // U_kk^-1 -> LDS (16 x 16-B loads per thread, all in flight)
@@ -1393,9 +1422,10 @@ __global__ __launch_bounds__(STRIP_THREADS, 2) void k_trsm_strips(PgmDev P, int 
 // The same kernel with dp=1 and a short row range is the in-panel update.
 // ---------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi) {
-  int b = blockIdx.z, bx = blockIdx.x;
-  xcd_batch_remap(bx, b);
+__global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi, RagClasses rc) {
+  int b = blockIdx.z, bx = blockIdx.x, nbr = P.nb;              // nbr: the block rows the tiles are counted for
+  if (rc.n) { if (!rag_decode(rc, bx, b, nbr)) return; if (r_hi > nbr) r_hi = nbr; }      // (trimmed ragged set: the member's own tiles, all of them real)
+  else xcd_batch_remap(bx, b);
   constexpr int SUB = NB / C::BM;
   static_assert(C::BM == C::BN, "square tiles");
   // (Single light curve: an XCD-aware 8x8 super-block order of the tiles was measured and rejected at N=4096: a whole
@@ -1408,12 +1438,13 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
   const int nR = P.need_grad ? kend + 1 : 0;              // inverse-factor tiles per block row
   int r = r_lo;
   for (; r < r_hi; ++r) {                                   // rows are few: linear decode
-    const int cnt = (P.nb - r) + nR;
+    const int cnt = (nbr - r) + nR;
     if (tile < cnt) break;
     tile -= cnt;
   }
-  const bool syrk = tile < P.nb - r;
-  const int j = syrk ? r + tile : tile - (P.nb - r);
+  const bool syrk = tile < nbr - r;
+  const int j = syrk ? r + tile : tile - (nbr - r);
+  if (P.trim && !rc.n) { const int own = own_rows(P, b); if (r >= own || (syrk && j >= own)) return; }   // (the box of a trimmed set: a tile the light curve does not have)
   const int pstart = (!syrk && j > k0) ? j : k0;            // V_pj vanishes for p < j
   const bool assign = !syrk && j >= k0;                      // first contribution to this R tile
   double* A = P.A + b * P.sA;
@@ -1460,7 +1491,9 @@ __device__ __forceinline__ void ainv_diag_item(const PgmDev& P, int jb, int sp, 
   const double* A = P.A + b * P.sA;
   const double* Vjj = P.Dinv + b * P.sDinv + ((int64_t)jb * 2 + 1) * NB * NB;
   const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-  const int nrows = (P.nb - jb) * NB;                      // rows jb*NB .. np-1
+  const int own = own_rows(P, b);
+  if (jb >= own) return;                                   // (uniform; trimmed ragged set: nobody reads these columns' sums)
+  const int nrows = (own - jb) * NB;                       // rows jb*NB .. the light curve's last
   const int per = ((nrows + AINV_SPLITS - 1) / AINV_SPLITS + 7) / 8 * 8;
   const int r0 = sp * per, r1 = min(nrows, r0 + per);
   auto ld = [&](int rr) -> double {
@@ -1504,7 +1537,7 @@ __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
 // workgroup per tile would leave most CUs idle behind a 40 us gradient epilogue): four workgroups per work item, a 64x64
 // sub-tile each -- launch index 4 * item + sub-tile, one row of partial sums per workgroup (P.nitems counts workgroups).
 template <int D, int ORDER, class C>
-__device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, int b, int bx) {
+__device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, int b, int bx, int rows = -1) {
   constexpr int SUB = NB / C::BM;                              // sub-tiles per side (1 or 2)
   static_assert(C::BM == C::BN && C::NT == NTHREADS && (SUB == 1 || SUB == 2), "whole tiles or quarter tiles");
   if (P.info[b] != 0) return;
@@ -1513,8 +1546,21 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
   // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
   // that no single workgroup sets the makespan; the contraction below is linear in the tile
   const int lb = bx;
-  const int4 item = P.items[lb / (SUB * SUB)];
-  const int i = item.x, j = item.y, p0 = item.z, plen = item.w & 0xffff;
+  // (rows >= 0, the 1-D grid of a trimmed ragged set with one work item per tile: the member's own tiles in triangular order)
+  int4 item;
+  if (rows >= 0) { int ti, tj; tri_decode(lb / (SUB * SUB), ti, tj); item = make_int4(ti, tj, tj, rows - tj); }
+  else item = P.items[lb / (SUB * SUB)];
+  const int i = item.x, j = item.y, p0 = item.z;
+  int plen = item.w & 0xffff;
+  const int own = rows >= 0 ? rows : own_rows(P, b);
+  if (P.trim && rows < 0) {                                    // (the box of a trimmed ragged set: block rows p0 .. of the light curve's own)
+    if (p0 >= own) {                                           // none (uniform): the item counts nothing, k_finalize sums a zero
+      double* part0 = P.partials + b * P.sPart + (int64_t)lb * P.nslot;
+      for (int s = threadIdx.x; s < P.nslot; s += NTHREADS) part0[s] = 0.0;
+      return;
+    }
+    if (plen > own - p0) plen = own - p0;
+  }
   const int mo = ((lb % (SUB * SUB)) / SUB) * C::BM, no = ((lb % (SUB * SUB)) % SUB) * C::BN;      // the sub-tile's place in the tile
   double* A = P.A + b * P.sA;
   const double* Dv = P.Dinv + b * P.sDinv;
@@ -1600,7 +1646,7 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
         const int m = mo + acc_row<C>(wp, ti, r), n = no + acc_col<C>(wp, tj);
         const int gi = i * NB + m, gj = j * NB + n;
         const bool valid = (gi < npts) && (gj < npts);
-        const double aa = (p0 + plen == P.nb) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile
+        const double aa = (p0 + plen == own) ? arow[m] * acol[n] : 0.0;     // alpha alpha^T enters once per tile: with its last block row
         // (shaped diagonal tile: an MFMA tile above the diagonal stands for its mirror image too, the ones that were not computed count nothing)
         const double wt = shape == SH_FULL ? sym : (tj < shape_tj_lo(shape, ti) ? 0.0 : (shape == SH_UPPER && ti == tj) ? 1.0 : 2.0);
         acc[ti][tj][r] = (valid && wt != 0.0) ? wt * (aa - acc[ti][tj][r]) : 0.0;
@@ -1809,7 +1855,7 @@ __device__ __forceinline__ void finalize_role(const PgmDev& P, int b, int role, 
       if (c_gmean) c_gmean[(int64_t)cb * cs + i] = al / (double)n;
       double dsum = 0.0;
       if (P.ainv_from_tiles) {
-        const int cnt = (P.nb - i / NB + P.ainv_from_tiles - 1) / P.ainv_from_tiles;      // work items of tile (jb, jb)
+        const int cnt = (own_rows(P, b) - i / NB + P.ainv_from_tiles - 1) / P.ainv_from_tiles;      // work items of tile (jb, jb) that have block rows
         for (int sp = 0; sp < cnt; ++sp) dsum += P.dpart[b * P.sDpart + (int64_t)sp * P.np + i];
       } else {
 #pragma unroll
@@ -1820,9 +1866,12 @@ __device__ __forceinline__ void finalize_role(const PgmDev& P, int b, int role, 
     }
     return;
   }
+  // (a member of a trimmed ragged set: its own block rows -- nothing was written beyond them -- and, with one work item per
+  //  tile, the partial sums of its own tiles)
+  const int own = own_rows(P, b), own_items = P.trim_tri ? own * (own + 1) / 2 : P.nitems;
   double s = 0.0;
-  for (int i = t; i < P.np; i += FIN_THREADS) { const double zi = P.z[b * P.sVec + i]; s += zi * zi; }
-  for (int kk = t; kk < P.nb; kk += FIN_THREADS) s += P.logdet[b * P.sLogdet + kk];
+  for (int i = t; i < own * NB; i += FIN_THREADS) { const double zi = P.z[b * P.sVec + i]; s += zi * zi; }
+  for (int kk = t; kk < own; kk += FIN_THREADS) s += P.logdet[b * P.sLogdet + kk];
   s = wave_sum(s);
   if ((t & 63) == 0) red[t >> 6] = s;
   __syncthreads();
@@ -1853,11 +1902,11 @@ __device__ __forceinline__ void finalize_role(const PgmDev& P, int b, int role, 
     const double* part = P.partials + b * P.sPart + sidx;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int tile = lane;
-    for (; tile + 192 < P.nitems; tile += 256) {
+    for (; tile + 192 < own_items; tile += 256) {
       a0 += part[(int64_t)tile * P.nslot]; a1 += part[(int64_t)(tile + 64) * P.nslot];
       a2 += part[(int64_t)(tile + 128) * P.nslot]; a3 += part[(int64_t)(tile + 192) * P.nslot];
     }
-    for (; tile < P.nitems; tile += 64) a0 += part[(int64_t)tile * P.nslot];
+    for (; tile < own_items; tile += 64) a0 += part[(int64_t)tile * P.nslot];
     double acc = wave_sum((a0 + a1) + (a2 + a3));   // fixed summation order: reproducible
     if (lane != 0) continue;
     double val = 0.0;
@@ -1883,11 +1932,11 @@ __global__ __launch_bounds__(FIN_THREADS_K) void k_finalize(PgmDev P) {
 }
 
 template <int D, int ORDER, class C>
-__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
-  int b = blockIdx.z, bx = blockIdx.x;
-  xcd_batch_remap(bx, b);
+__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P, RagClasses rc) {
+  int b = blockIdx.z, bx = blockIdx.x, rows = -1;
+  if (rc.n) { if (!rag_decode(rc, bx, b, rows)) return; } else xcd_batch_remap(bx, b);
   __shared__ __attribute__((aligned(16))) double lds[CfgBig::LDS_DOUBLES];
-  lauum_grad_item<D, ORDER, C>(P, lds, b, bx);
+  lauum_grad_item<D, ORDER, C>(P, lds, b, bx, rows);
 }
 
 // ---------------------------------------------------------------------------

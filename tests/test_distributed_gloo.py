@@ -169,28 +169,41 @@ def test_ragged_batch_over_ranks_is_the_single_process_result(total, world):
     assert torch.equal(alone["mll"], ref_ll[total - 1])
 
 
-def test_ragged_launch_sets_follow_the_cost_model():
-    """``pgm_ragged_plan`` (host only): light curves are grouped by block-row count, longest first; a short group joins the
-    set above it only where padding is cheaper than a launch set of its own; sets never exceed the workspace's batch."""
+def test_ragged_launch_sets_follow_the_cost_model(monkeypatch):
+    """``pgm_ragged_plan`` (host only): light curves are taken by block-row count, longest first.  Sixteen and more of them
+    (256 block rows in all) form ONE trimmed set -- every member stops at its own last block row -- except stragglers at the
+    long end; fewer, or ``PGM_RAGGED_TRIM=0``: padded sets -- a short group joins the set above it only where padding is
+    cheaper than a launch set of its own.  Sets never exceed the workspace's batch."""
     from pgmuvi_amd import _hip
-    # 9 block-row counts with 57 light curves each (512 x N ~ U(1024, 2048)): every count its own set
-    lengths = [1025 + 128 * k for k in range(8) for _ in range(57)] + [900] * 57
-    set_of, nbs = _hip.ragged_plan(lengths, 512)
-    assert nbs == [16, 15, 14, 13, 12, 11, 10, 9, 8] and len(set(set_of)) == 9
-    assert all(nbs[s2] == (n + 127) // 128 for s2, n in zip(set_of, lengths))
-    # a lone light curve of 15 block rows rides with the 16-block-row set; 40 of them do not (40 * (16^3 - 15^3) * 0.044 > 15 * 60)
-    set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900], 512)
+    lengths = [1025 + 128 * k for k in range(8) for _ in range(57)] + [900] * 57          # 9 block-row counts, 57 light curves each
+    set_of, nbs = _hip.ragged_plan(lengths, 1024)
     assert nbs == [16] and set(set_of) == {0}
+    set_of, nbs = _hip.ragged_plan(lengths, 512)                 # 513 light curves: the last one does not fit the first set
+    assert nbs == [16, 8] and set_of.count(0) == 512 and set_of.count(1) == 1
     set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900] * 40, 512)
-    assert nbs == [16, 15]
-    # order of the caller is kept inside a set, and the answer does not depend on it
-    set_of, nbs = _hip.ragged_plan([200, 2300, 640, 2300, 130], 512)
+    assert nbs == [16]
+    # stragglers: three light curves of 32 block rows among a hundred of 4 keep to themselves (a padded set, the fused sweep)
+    set_of, nbs = _hip.ragged_plan([512] * 50 + [4096] * 3 + [500] * 50, 512)
+    assert nbs == [32, 4] and [set_of.count(k) for k in range(2)] == [3, 100] and set_of[50:53] == [0, 0, 0]
+    # ... but eight that share their upper half of block rows are company enough
+    set_of, nbs = _hip.ragged_plan([512] * 50 + [4096] * 3 + [2500] * 5, 512)
+    assert nbs == [32] and set(set_of) == {0}
+    # fewer than 16 light curves: padded sets
+    set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900], 512)     # a lone light curve of 15 block rows rides with the 16-block-row set
+    assert nbs == [16] and set(set_of) == {0}
+    set_of, nbs = _hip.ragged_plan([200, 2300, 640, 2300, 130], 512)   # the caller's order is kept inside a set, the answer does not depend on it
     assert nbs[0] == 18 and set_of[1] == set_of[3] == 0
-    # more members than the workspace holds: split
-    set_of, nbs = _hip.ragged_plan([512] * 20, 8)
+    set_of, nbs = _hip.ragged_plan([512] * 20, 8)                 # more members than the workspace holds: split
     assert nbs == [4, 4, 4] and [set_of.count(k) for k in range(3)] == [8, 8, 4]
     with pytest.raises(RuntimeError):
         _hip.ragged_plan([0, 5], 4)
+    # the padded sets of many light curves (round 4's first form)
+    monkeypatch.setenv("PGM_RAGGED_TRIM", "0")
+    set_of, nbs = _hip.ragged_plan(lengths, 512)                 # every count its own set
+    assert nbs == [16, 15, 14, 13, 12, 11, 10, 9, 8] and len(set(set_of)) == 9
+    assert all(nbs[s2] == (n + 127) // 128 for s2, n in zip(set_of, lengths))
+    set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900] * 40, 512)     # 40 * (16^3 - 15^3) * 0.044 > 15 * 60
+    assert nbs == [16, 15]
 
 
 def test_partitioning_rules():

@@ -228,6 +228,58 @@ def test_ragged_batch_equals_singles_and_oracle(dev):
         assert _rel(small[f"g_{p}"].reshape(-1), out[f"g_{p}"].reshape(-1)) < 1e-10
 
 
+def test_trimmed_ragged_set_against_padded_sets_and_singles(dev, monkeypatch):
+    """40 light curves of 2 .. 12 block rows: by default ONE trimmed launch set of the panel sweep (every member stops at its own
+    last block row: the workgroups of tiles it does not have leave at once) -- against the padded sets of ``PGM_RAGGED_TRIM=0``
+    (two sets, of 12 and of 4 block rows, the shorter members padded with identity blocks): the same
+    value bit for bit -- every tile receives its sources in ascending order whatever the sweep -- and gradients equal to the
+    rounding of their differently split sums; a few members against their own single evaluation and the oracle; a member
+    that is not positive definite inside a trimmed set; value-only."""
+    rng = np.random.default_rng(23)
+    lengths = [int(v) for v in rng.integers(130, 1537, size=40)]
+    lengths[7], lengths[31] = 1536, 130
+    curves = _ragged_curves(lengths, first=100)
+    outs = {}
+    for mode in ("1", "0"):
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_RAGGED_TRIM", mode)
+        set_of, nbs = _hip.ragged_plan(lengths, 64)
+        assert nbs == ([12] if mode == "1" else [12, 4])
+        o = evaluate_ragged(curves, device=dev)
+        o0 = evaluate_ragged(curves, device=dev, need_grad=False)
+        torch.cuda.synchronize()
+        assert torch.equal(o["mll"], o0["mll"])
+        outs[mode] = o
+    monkeypatch.delenv("PGM_RAGGED_TRIM")
+    _hip.release_workspaces()
+    a, b_ = outs["1"], outs["0"]
+    assert int(a["info"].abs().max()) == 0 and torch.equal(a["mll"], b_["mll"])
+    for p in ("w", "mu", "v"):
+        assert _rel(a[f"g_{p}"].reshape(-1), b_[f"g_{p}"].reshape(-1)) < 1e-10, p
+    for i, n in enumerate(lengths):
+        assert a["g_noise"][i].shape == (n,) and _rel(a["g_noise"][i], b_["g_noise"][i]) < 1e-10 and _rel(a["g_mean"][i], b_["g_mean"][i]) < 1e-10
+    for i in (7, 31, 0, 19):
+        c, n = curves[i], lengths[i]
+        single = _hip_eval(dev, c["x"].reshape(n, 1), c["y"], c["mean"], c["noise"], c["w"], c["mu"], c["v"])
+        assert float(single["mll"]) == float(a["mll"][i]), (i, n)
+        for p in ("w", "mu", "v"):
+            assert _rel(single[f"g_{p}"].reshape(-1), a[f"g_{p}"][i].reshape(-1)) < 1e-10, (i, n, p)
+        val, gr = orc.mll_value_grad_closed_form(c["x"].reshape(n, 1), c["y"], c["mean"].expand(n), c["noise"], c["w"], c["mu"], c["v"])
+        assert abs(float(val) - float(a["mll"][i])) < MLL_TOL, (i, n)
+        for p in ("w", "mu", "v"):
+            assert _rel(a[f"g_{p}"][i].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, (i, n, p)
+        assert _rel(a["g_noise"][i], gr["noise"]) < GRAD_RTOL and _rel(a["g_mean"][i], gr["mean"]) < GRAD_RTOL
+    # a member that is not positive definite: its pivot, NaNs; the others keep their bits
+    bad = [dict(c) for c in curves]
+    bad[12]["noise"] = -5.0 * torch.ones(lengths[12], dtype=D)
+    ob = evaluate_ragged(bad, device=dev)
+    torch.cuda.synchronize()
+    info = ob["info"].cpu().tolist()
+    assert info[12] > 0 and sum(1 for v_ in info if v_ != 0) == 1 and math.isnan(float(ob["mll"][12]))
+    keep = [i for i in range(40) if i != 12]
+    assert torch.equal(ob["mll"][keep], a["mll"][keep]) and torch.equal(ob["g_mu"][keep], a["g_mu"][keep])
+
+
 def test_ragged_set_is_bit_for_bit_the_equal_length_batch(dev):
     """Inside a launch set every light curve runs the schedule of the set's (block rows, members): a member whose own block
     rows are the set's gets, gradients included, the bits of the equal-length batched call of the same shape; and padded

@@ -1,6 +1,8 @@
-"""Ragged batches on one GPU: B light curves with N ~ U{n_lo..n_hi} through the ragged entry point
-(launch sets that share a chain length) against the same number of light curves padded to n_hi in the equal-length batched
-call.  tools/raggedbench.py [B] [n_lo] [n_hi] [reps]"""
+"""Ragged batches on one GPU: B light curves with N ~ U{n_lo..n_hi} through the ragged entry point --
+one trimmed launch set (every member stops at its own last block row), and with PGM_RAGGED_TRIM=0 the padded launch sets of
+(nearly) equal block rows, one after the other and two at a time -- against the same number of light curves padded to n_hi in
+the equal-length batched call.  tools/raggedbench.py [B] [n_lo] [n_hi] [reps]"""
+import os
 import sys
 import time
 
@@ -23,8 +25,6 @@ for i, n in enumerate(lengths):
     curves.append(dict(x=t.double(), y=y.double(), noise=e.double() ** 2, mean=h["mean"], w=h["w"], mu=h["mu"], v=h["v"]))
 padded, lens = pad_curves(curves, device=dev)
 chunk = default_chunk(n_hi, device=dev)
-set_of, nbs = _hip.ragged_plan(lengths, min(B, chunk))
-print(f"{B} light curves, N ~ U{{{n_lo}..{n_hi}}}: {len(nbs)} launch sets, block rows {nbs}, members {[set_of.count(k) for k in range(len(nbs))]}")
 
 
 def timed(f):
@@ -36,12 +36,27 @@ def timed(f):
     return best * 1e3
 
 
-rag1 = timed(lambda: evaluate_ragged(padded=padded, lengths=lens, chunk=chunk, streams=1))
+work = sum(float(n) ** 3 for n in lengths)
+rate = lambda ms: f"{ms:.2f} ms per pass = {B / ms * 1e3:.0f} evaluations/s, {work / ms * 1e-9:.1f} TFLOP/s on the light curves' own N^3 ({work / ms * 1e-9 / 78.6:.3f} of the fp64 MFMA peak)"
+set_of, nbs = _hip.ragged_plan(lengths, min(B, chunk))
+print(f"{B} light curves, N ~ U{{{n_lo}..{n_hi}}}: {len(nbs)} launch set(s), block rows {nbs}, members {[set_of.count(k) for k in range(len(nbs))]}")
 rag = timed(lambda: evaluate_ragged(padded=padded, lengths=lens, chunk=chunk))
 out = evaluate_ragged(padded=padded, lengths=lens, chunk=chunk)
+torch.cuda.synchronize()
+print(f"ragged entry point (trimmed set: the default): {rate(rag)}; info max {int(out['info'].abs().max())}")
+_hip.release_workspaces()
+os.environ["PGM_RAGGED_TRIM"] = "0"
+set_of, nbs = _hip.ragged_plan(lengths, min(B, chunk))
+print(f"PGM_RAGGED_TRIM=0: {len(nbs)} padded launch sets, block rows {nbs}, members {[set_of.count(k) for k in range(len(nbs))]}")
+rag1 = timed(lambda: evaluate_ragged(padded=padded, lengths=lens, chunk=chunk, streams=1))
+rag2 = timed(lambda: evaluate_ragged(padded=padded, lengths=lens, chunk=chunk))
 out1 = evaluate_ragged(padded=padded, lengths=lens, chunk=chunk, streams=1)
 torch.cuda.synchronize()
-assert torch.equal(out["mll"], out1["mll"])
+assert torch.equal(out["mll"], out1["mll"])                    # (the value does not depend on the sets)
+print(f"   the sets one after the other on one stream: {rate(rag1)}")
+print(f"   two sets at a time (two streams, two workspaces): {rate(rag2)}")
+del os.environ["PGM_RAGGED_TRIM"]
+_hip.release_workspaces()
 # the same light curves padded to n_hi points each (what the equal-length call forces on a caller): the cfg-3 recipe at n_hi
 xs, ys, ms, ns, ws, mus, vs = [], [], [], [], [], [], []
 for i in range(min(B, 64)):
@@ -53,10 +68,5 @@ rep = (B + len(xs) - 1) // len(xs)
 st = lambda L: torch.stack(L).repeat(rep, *([1] * L[0].dim()))[:B].to(dev).contiguous()
 x, y, m, nz, w, mu, v = st(xs), st(ys), st(ms), st(ns), st(ws), st(mus), st(vs)
 eq = timed(lambda: evaluate_batch(x, y, m, nz, w, mu, v, chunk=chunk))
-work = sum(float(n) ** 3 for n in lengths)
-print(f"ragged entry point, the sets one after the other on one stream: {rag1:.2f} ms per pass = {B / rag1 * 1e3:.0f} evaluations/s "
-      f"({work / rag1 * 1e-9 / 78.6:.3f} of the fp64 MFMA peak on the light curves' own N^3)")
-print(f"ragged entry point, two launch sets at a time (two streams, two workspaces: evaluate_ragged's default): {rag:.2f} ms per pass = {B / rag * 1e3:.0f} evaluations/s, {work / rag * 1e-9:.1f} TFLOP/s on the light curves' own N^3 "
-      f"({work / rag * 1e-9 / 78.6:.3f} of the fp64 MFMA peak); info max {int(out['info'].abs().max())}")
 print(f"padded to N={n_hi}, equal-length call: {eq:.2f} ms per pass = {B / eq * 1e3:.0f} evaluations/s   (ragged / padded time: {rag / eq:.3f}; "
       f"sum N^3 / B n_hi^3 = {work / (B * float(n_hi) ** 3):.3f})")
