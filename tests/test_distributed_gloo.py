@@ -170,8 +170,8 @@ def test_ragged_batch_over_ranks_is_the_single_process_result(total, world):
 
 
 def test_ragged_launch_sets_follow_the_cost_model(monkeypatch):
-    """``pgm_ragged_plan`` (host only): light curves are taken by block-row count, longest first.  Sixteen and more of them
-    (256 block rows in all) form ONE trimmed set -- every member stops at its own last block row -- except stragglers at the
+    """``pgm_ragged_plan`` (host only): light curves are taken by block-row count, longest first.  Twelve and more of them
+    (160 block rows in all) form ONE trimmed set -- every member stops at its own last block row -- except stragglers at the
     long end; fewer, or ``PGM_RAGGED_TRIM=0``: padded sets -- a short group joins the set above it only where padding is
     cheaper than a launch set of its own.  Sets never exceed the workspace's batch."""
     from pgmuvi_amd import _hip
@@ -188,7 +188,7 @@ def test_ragged_launch_sets_follow_the_cost_model(monkeypatch):
     # ... but eight that share their upper half of block rows are company enough
     set_of, nbs = _hip.ragged_plan([512] * 50 + [4096] * 3 + [2500] * 5, 512)
     assert nbs == [32] and set(set_of) == {0}
-    # fewer than 16 light curves: padded sets
+    # fewer than 12 light curves: padded sets
     set_of, nbs = _hip.ragged_plan([2048] * 10 + [1900], 512)     # a lone light curve of 15 block rows rides with the 16-block-row set
     assert nbs == [16] and set(set_of) == {0}
     set_of, nbs = _hip.ragged_plan([200, 2300, 640, 2300, 130], 512)   # the caller's order is kept inside a set, the answer does not depend on it

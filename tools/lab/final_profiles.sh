@@ -8,6 +8,12 @@ bash tools/profile.sh batch512_n2048 2048 2 1 4 512
 bash tools/profile.sh cfg4_n8192_d2 8192 3 1 3 1 2
 bash tools/profile.sh cfg5_tick_8x2048 2048 5 1 4 8
 bash tools/profile.sh batch256_n4096 4096 1 1 4 256
+# the ragged batch of tools/raggedbench.py (512 light curves, N ~ U{1024..2048}: one trimmed launch set): kernel statistics and timeline
+mkdir -p gpurun_out/prof_ragged512
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ragged512 -o stats -- python3 tools/lab/ragprof.py 512 1024 2048 3 > gpurun_out/prof_ragged512/stats.log 2>&1
+s=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_ragged512/kernel_stats.csv
+k=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_trace.csv' | head -1); python3 tools/timeline.py "$k" > gpurun_out/prof_ragged512/timeline.txt
+find gpurun_out/prof_ragged512 -name '*_kernel_trace.csv' -delete
 mkdir -p gpurun_out/prof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o stats -- python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu > gpurun_out/prof_bench/bench_line.json 2> gpurun_out/prof_bench/bench.err
 s=$(find gpurun_out/prof_bench -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_bench/kernel_stats.csv
