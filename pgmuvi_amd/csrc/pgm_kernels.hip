@@ -1305,11 +1305,13 @@ __global__ __launch_bounds__(T16_THREADS) void k_trsm16(PgmDev P, int k, int nsl
 // groups, the four 32-row groups top to bottom): same bits as k_trsm.
 // ---------------------------------------------------------------------------
 constexpr int STRIP_THREADS = 512, STRIP_W = 16;
+// (TRIM: a trimmed ragged launch set -- a kernel of its own, so that the equal-length path keeps its code to the instruction)
+template <bool TRIM>
 __global__ __launch_bounds__(STRIP_THREADS, 2) void k_trsm_strips(PgmDev P, int k, int nblocks) {
   __shared__ __attribute__((aligned(16))) double Ui[NB * PM];
   __shared__ double zs[NB];
   const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
-  {   // (trimmed ragged set: the light curve's own block columns only -- they are the first ones of the strip order)
+  if constexpr (TRIM) {   // (the light curve's own block columns only -- they are the first ones of the strip order)
     const int own = own_rows(P, b);
     if (k >= own) return;
     nblocks -= P.nb - own;
@@ -1421,11 +1423,19 @@ __global__ __launch_bounds__(STRIP_THREADS, 2) void k_trsm_strips(PgmDev P, int 
 // which, not MFMA issue, bounds a K=128 update on this machine.
 // The same kernel with dp=1 and a short row range is the in-panel update.
 // ---------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi, RagClasses rc) {
+// RAG: a trimmed ragged launch set (`rc`) -- an instantiation of its own, so that the equal-length path keeps its code to the
+// instruction (with the class table as an argument of the one kernel, its workgroups waited for two kernel-argument round trips
+// instead of one: 512 x N=2048 +0.85 % in this kernel)
+struct NoClasses {};
+template <class C, bool RAG>
+__global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, int r_lo, int r_hi, std::conditional_t<RAG, RagClasses, NoClasses> rc) {
   int b = blockIdx.z, bx = blockIdx.x, nbr = P.nb;              // nbr: the block rows the tiles are counted for
-  if (rc.n) { if (!rag_decode(rc, bx, b, nbr)) return; if (r_hi > nbr) r_hi = nbr; }      // (trimmed ragged set: the member's own tiles, all of them real)
-  else xcd_batch_remap(bx, b);
+  bool classes = false;
+  if constexpr (RAG) {
+    classes = rc.n != 0;
+    if (classes) { if (!rag_decode(rc, bx, b, nbr)) return; if (r_hi > nbr) r_hi = nbr; }      // (the member's own tiles, all of them real)
+  }
+  if (!classes) xcd_batch_remap(bx, b);
   constexpr int SUB = NB / C::BM;
   static_assert(C::BM == C::BN, "square tiles");
   // (Single light curve: an XCD-aware 8x8 super-block order of the tiles was measured and rejected at N=4096: a whole
@@ -1444,7 +1454,9 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
   }
   const bool syrk = tile < nbr - r;
   const int j = syrk ? r + tile : tile - (nbr - r);
-  if (P.trim && !rc.n) { const int own = own_rows(P, b); if (r >= own || (syrk && j >= own)) return; }   // (the box of a trimmed set: a tile the light curve does not have)
+  if constexpr (RAG) {
+    if (P.trim && !classes) { const int own = own_rows(P, b); if (r >= own || (syrk && j >= own)) return; }   // (the box of a trimmed set: a tile the light curve does not have)
+  }
   const int pstart = (!syrk && j > k0) ? j : k0;            // V_pj vanishes for p < j
   const bool assign = !syrk && j >= k0;                      // first contribution to this R tile
   double* A = P.A + b * P.sA;
@@ -1932,9 +1944,17 @@ __global__ __launch_bounds__(FIN_THREADS_K) void k_finalize(PgmDev P) {
 }
 
 template <int D, int ORDER, class C>
-__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P, RagClasses rc) {
-  int b = blockIdx.z, bx = blockIdx.x, rows = -1;
-  if (rc.n) { if (!rag_decode(rc, bx, b, rows)) return; } else xcd_batch_remap(bx, b);
+__global__ __launch_bounds__(256, 2) void k_lauum_grad(PgmDev P) {
+  int b = blockIdx.z, bx = blockIdx.x;
+  xcd_batch_remap(bx, b);
+  __shared__ __attribute__((aligned(16))) double lds[CfgBig::LDS_DOUBLES];
+  lauum_grad_item<D, ORDER, C>(P, lds, b, bx);
+}
+// ... of a trimmed ragged launch set with one work item per tile: the 1-D grid of the members' own tiles (RagClasses)
+template <int D, int ORDER, class C>
+__global__ __launch_bounds__(256, 2) void k_lauum_grad_rag(PgmDev P, RagClasses rc) {
+  int b = 0, bx = 0, rows = -1;
+  if (!rag_decode(rc, bx, b, rows)) return;
   __shared__ __attribute__((aligned(16))) double lds[CfgBig::LDS_DOUBLES];
   lauum_grad_item<D, ORDER, C>(P, lds, b, bx, rows);
 }
