@@ -141,7 +141,7 @@ __device__ __forceinline__ void load_frag(const __amdgpu_buffer_rsrc_t rs, int v
 }
 struct OperandBlock { __amdgpu_buffer_rsrc_t ra, rb; int voa, vob, sa, sb; };   // descriptors, lane offsets, bytes per k-step
 template <class C, class PtrFn>
-__device__ __forceinline__ void gemm_direct(int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late) {
+__device__ __forceinline__ void gemm_direct(int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late, int skip_ks = 0) {
   const WavePos wp = wave_pos<C>();
   constexpr int PD = C::PF, TM = C::TM, TN = C::TN, KS = NB / 4;      // k-steps per k-block
   static_assert(KS % PD == 0 && PD < KS, "prefetch distance");
@@ -163,7 +163,8 @@ __device__ __forceinline__ void gemm_direct(int nkb, PtrFn&& ptrs, v4d (&acc)[C:
     const int kr = ks % KS;
     load_frag<TM>(o.ra, o.voa, kr * o.sa, a[u]); load_frag<TN>(o.rb, o.vob, kr * o.sb, b[u]);
   };
-  const int nks = nkb * KS;
+  // (skip_ks: k-steps left out at the END of the last k-block -- rows the caller knows to be zero, a multiple of PD)
+  const int nks = nkb * KS - skip_ks;
 #pragma unroll
   for (int u = 0; u < PD; ++u) load(u, u);
   if (negate_late) {                                                   // acc holds +C from acc_load_raw: its loads and the first
@@ -201,7 +202,7 @@ __device__ __forceinline__ int shape_tj_lo(int shape, int ti) {       // the com
   return shape == SH_FULL ? 0 : shape == SH_UPPER ? ti : shape == SH_ROWS_LO ? (ti < 2 ? 0 : 4) : (ti >= 2 ? 0 : 4);
 }
 template <class C, int SH, class PtrFn>
-__device__ __forceinline__ void gemm_direct_shaped(const WavePos wp, int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late) {
+__device__ __forceinline__ void gemm_direct_shaped(const WavePos wp, int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late, int skip_ks = 0) {
   static_assert(C::DIRECT && C::TM == 4 && C::TN == 4, "shaped tiles: the direct 64x64-per-wavefront form");
   constexpr int PD = C::PF, TM = C::TM, TN = C::TN, KS = NB / 4;
   constexpr int TA = (SH == SH_ROWS_LO || SH == SH_ROWS_HI) ? 2 : TM, A0 = SH == SH_ROWS_HI ? 2 : 0;   // A fragments: rows A0 .. A0 + TA - 1
@@ -223,7 +224,7 @@ __device__ __forceinline__ void gemm_direct_shaped(const WavePos wp, int nkb, Pt
     const int kr = ks % KS;
     load_frag<TA>(o.ra, o.voa, kr * o.sa, a[u]); load_frag<TN>(o.rb, o.vob, kr * o.sb, b[u]);
   };
-  const int nks = nkb * KS;
+  const int nks = nkb * KS - skip_ks;
 #pragma unroll
   for (int u = 0; u < PD; ++u) load(u, u);
   if (negate_late) {
@@ -279,8 +280,8 @@ __device__ __forceinline__ void acc_clear_outside(v4d (&acc)[C::TM][C::TN]) {
 // separate column slabs multiplied as one operand).
 template <class C, class PtrFn>
 __device__ __forceinline__ void gemm_tn(double* __restrict__ lds, int nkb, PtrFn&& ptrs,
-                                        v4d (&acc)[C::TM][C::TN], int bsplit = 0, bool negate_late = false) {
-  if constexpr (C::DIRECT) { gemm_direct<C>(nkb, ptrs, acc, negate_late); return; }   // (bsplit: staged form only)
+                                        v4d (&acc)[C::TM][C::TN], int bsplit = 0, bool negate_late = false, int skip_ks = 0) {
+  if constexpr (C::DIRECT) { gemm_direct<C>(nkb, ptrs, acc, negate_late, skip_ks); return; }   // (bsplit: staged form only; skip_ks: direct form only)
   const int t = threadIdx.x;
   const WavePos wp = wave_pos<C>();
   constexpr int KC = C::KC;

@@ -1465,6 +1465,24 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
   double* Cp = A + ((int64_t)r * NB + si * C::BM) * ld + j * NB + sj * C::BN;
   __shared__ __attribute__((aligned(16))) double lds[C::LDS_DOUBLES];
   v4d acc[C::TM][C::TN];
+  if constexpr (RAG) {
+    // A light curve's last block ends in identity padding (n is no multiple of 128): a wavefront whose whole sub-tile lies in the
+    // padded rows of block row r or the padded columns of block column j would subtract exact zeros -- it leaves at once (the
+    // first visit of a tile of the inverse factor stores its zeros); the direct loop has no barrier, the wavefronts of a tile do
+    // not wait for one another.  512 x N ~ U{1024..2048}: 5.4 % of this kernel's products.
+    static_assert(C::DIRECT, "wavefronts leave on their own: no barrier in the multiply loop");
+    if (P.trim) {
+      const int own = classes ? nbr : own_rows(P, b);
+      const int rem = P.nvec[b] - (own - 1) * NB;               // points in the last block
+      if (rem < NB && (r == own - 1 || j == own - 1)) {
+        const WavePos wq = wave_pos<C>();
+        if ((r == own - 1 && si * C::BM + wq.m0 >= rem) || (j == own - 1 && sj * C::BN + wq.n0 >= rem)) {
+          if (assign) { acc_zero<C>(acc); acc_store<C>(Cp, ld, acc, -1.0); }
+          return;
+        }
+      }
+    }
+  }
   if (assign) acc_zero<C>(acc); else acc_load_raw<C>(Cp, ld, acc);   // (negated inside gemm_tn: see negate_late there)
   gemm_tn<C>(lds, kend - pstart + 1, [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = pstart + kb;
@@ -1601,15 +1619,19 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
     if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB + no; ldb = ld; }
     else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB + no; ldb = NB; }
   };
+  // (a member of a trimmed ragged set whose last block ends in padding: the rows of V beyond its last point are zero, whole
+  //  groups of 16 of them are left out of the item's last k-block -- 512 x N ~ U{1024..2048}: 8 % of the pass's products)
+  int skip_ks = 0;
+  if (rows >= 0 && p0 + plen == own) skip_ks = ((own * NB - pts(P, b)) / 16) * 4;
   auto full_tile = [&]() {
     if (cont) acc_load_raw<C>(Rt, ld, acc, wp); else acc_zero<C>(acc);      // (negated inside gemm_tn)
-    gemm_tn<C>(lds, plen, operands, acc, 0, cont);
+    gemm_tn<C>(lds, plen, operands, acc, 0, cont, skip_ks);
   };
   if constexpr (SUB == 1 && C::DIRECT) {
     if (shape == SH_FULL) full_tile();
-    else if (shape == SH_UPPER) { acc_init_shaped<C, SH_UPPER>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_UPPER>(wp, plen, operands, acc, cont); acc_clear_outside<C, SH_UPPER>(acc); }
-    else if (shape == SH_ROWS_LO) { acc_init_shaped<C, SH_ROWS_LO>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_ROWS_LO>(wp, plen, operands, acc, cont); acc_clear_outside<C, SH_ROWS_LO>(acc); }
-    else { acc_init_shaped<C, SH_ROWS_HI>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_ROWS_HI>(wp, plen, operands, acc, cont); acc_clear_outside<C, SH_ROWS_HI>(acc); }
+    else if (shape == SH_UPPER) { acc_init_shaped<C, SH_UPPER>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_UPPER>(wp, plen, operands, acc, cont, skip_ks); acc_clear_outside<C, SH_UPPER>(acc); }
+    else if (shape == SH_ROWS_LO) { acc_init_shaped<C, SH_ROWS_LO>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_ROWS_LO>(wp, plen, operands, acc, cont, skip_ks); acc_clear_outside<C, SH_ROWS_LO>(acc); }
+    else { acc_init_shaped<C, SH_ROWS_HI>(Rt, ld, acc, wp); gemm_direct_shaped<C, SH_ROWS_HI>(wp, plen, operands, acc, cont, skip_ks); acc_clear_outside<C, SH_ROWS_HI>(acc); }
   } else {
     full_tile();
   }
