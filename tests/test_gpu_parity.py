@@ -280,6 +280,40 @@ def test_trimmed_ragged_set_against_padded_sets_and_singles(dev, monkeypatch):
     assert torch.equal(ob["mll"][keep], a["mll"][keep]) and torch.equal(ob["g_mu"][keep], a["g_mu"][keep])
 
 
+def test_trimmed_ragged_sets_of_short_light_curves_and_of_more_than_the_workspace_holds(dev):
+    """The ends of the trimmed form: 160 light curves of 20 .. 300 points (one to three block rows: the set's sweep is a single
+    panel, most members leave after their first block row) and the same batch through a workspace of 64 slots (three trimmed
+    sets, one after the other) -- every value bit for bit the light curve's own single evaluation, gradients to rounding, a few
+    against the oracle."""
+    rng = np.random.default_rng(5)
+    lengths = [int(v) for v in rng.integers(20, 301, size=160)]
+    lengths[0], lengths[1], lengths[2] = 300, 20, 128
+    curves = _ragged_curves(lengths, first=200)
+    set_of, nbs = _hip.ragged_plan(lengths, 160)
+    assert nbs == [3]
+    set_of, nbs = _hip.ragged_plan(lengths, 64)
+    assert len(nbs) == 3 and [set_of.count(k) for k in range(3)] == [64, 64, 32]
+    out = evaluate_ragged(curves, device=dev)
+    part = evaluate_ragged(curves, device=dev, chunk=64)
+    torch.cuda.synchronize()
+    assert int(out["info"].abs().max()) == 0 and torch.equal(out["mll"], part["mll"])
+    for p in ("w", "mu", "v"):
+        assert _rel(out[f"g_{p}"].reshape(-1), part[f"g_{p}"].reshape(-1)) < 1e-10, p
+    for i in list(range(0, 160, 9)) + [1, 2]:
+        c, n = curves[i], lengths[i]
+        single = _hip_eval(dev, c["x"].reshape(n, 1), c["y"], c["mean"], c["noise"], c["w"], c["mu"], c["v"])
+        assert float(single["mll"]) == float(out["mll"][i]), (i, n)
+        for p in ("w", "mu", "v"):
+            assert _rel(single[f"g_{p}"].reshape(-1), out[f"g_{p}"][i].reshape(-1)) < 1e-10, (i, n, p)
+        assert _rel(single["g_noise"], out["g_noise"][i]) < 1e-10 and _rel(single["g_mean"], out["g_mean"][i]) < 1e-10
+    for i in (0, 1, 77):
+        c, n = curves[i], lengths[i]
+        val, gr = orc.mll_value_grad_closed_form(c["x"].reshape(n, 1), c["y"], c["mean"].expand(n), c["noise"], c["w"], c["mu"], c["v"])
+        assert abs(float(val) - float(out["mll"][i])) < MLL_TOL, (i, n)
+        for p in ("w", "mu", "v"):
+            assert _rel(out[f"g_{p}"][i].reshape(-1), gr[p].reshape(-1)) < GRAD_RTOL, (i, n, p)
+
+
 def test_ragged_set_is_bit_for_bit_the_equal_length_batch(dev):
     """Inside a launch set every light curve runs the schedule of the set's (block rows, members): a member whose own block
     rows are the set's gets, gradients included, the bits of the equal-length batched call of the same shape; and padded
