@@ -92,3 +92,81 @@ def test_collisions_and_extremes_against_the_oracle(case):
         a, b = out[f"g_{p}"].detach().cpu().double().reshape(-1), gr[p].reshape(-1).double()
         assert float((a - b).abs().max() / (b.abs().max() + 1e-300)) < 1e-7, (case, p)
     _hip.release_workspaces()
+
+
+def test_random_ragged_batches_against_their_single_evaluations():
+    """Random ragged batches through ``pgm_mll_value_grad_ragged_f64``: 12 .. 70 light curves per call (trimmed launch sets of the
+    panel sweep, and a few calls below the threshold: padded sets), lengths from 20 to 1400 in different mixes (uniform, many
+    equal ones, a few long stragglers), 1 .. 4 mixture components, 1-D and 2-D inputs in both dimension orders, noise vector
+    and / or one learned scalar per light curve, with and without the gradient.  Every value must be the light curve's own
+    single evaluation bit for bit, every gradient equal to it to rounding; one member per call also goes to the CPU oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("-m gpu tests need the MI355X")
+    dev = torch.device("cuda:0")
+    cases = int(os.environ.get("PGM_FUZZ_RAGGED_CASES", "8"))
+    gen = torch.Generator().manual_seed(int(os.environ.get("PGM_FUZZ_SEED", "20261004")) + 1)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    for c in range(cases):
+        B = (ri(28, 70) if c % 3 == 1 else ri(12, 70)) if c % 4 else ri(3, 11)     # (2-D cases: enough members for a trimmed set)
+        mix = c % 3
+        if mix == 0:
+            lengths = [ri(20, 1400) for _ in range(B)]
+        elif mix == 1:
+            lengths = [(640 if ri(0, 2) else ri(100, 900)) for _ in range(B)]
+        else:
+            lengths = [ri(20, 300) for _ in range(B)]
+            lengths[ri(0, B - 1)] = 1400; lengths[ri(0, B - 1)] = 1290
+        q = ri(1, 4); d = 2 if c % 3 == 1 else 1
+        order = ri(0, 1) if d == 2 else 0
+        S = max(lengths)
+        use_vec = c % 5 != 4
+        use_scalar = (not use_vec) or c % 2 == 0
+        x = torch.zeros(B, S, d, dtype=D); y = torch.zeros(B, S, dtype=D); nz = torch.zeros(B, S, dtype=D)
+        for b, n in enumerate(lengths):
+            xb = torch.rand(n, d, generator=gen, dtype=D) * 800.0
+            if d == 1:
+                xb = torch.sort(xb[:, 0])[0].reshape(n, 1)
+            else:
+                xb[:, 1] = torch.randint(1, 4, (n,), generator=gen).double() * 0.5
+            x[b, :n] = xb
+            y[b, :n] = torch.randn(n, generator=gen, dtype=D)
+            nz[b, :n] = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+        ns = 0.02 + 0.1 * torch.rand(B, generator=gen, dtype=D)
+        w = 0.1 + torch.rand(B, q, generator=gen, dtype=D)
+        mu = 0.005 + 0.3 * torch.rand(B, q, d, generator=gen, dtype=D)
+        v = 0.001 + 0.02 * torch.rand(B, q, d, generator=gen, dtype=D)
+        mean = (torch.randn(B, 1, generator=gen, dtype=D) * 0.3).expand(B, S).contiguous()
+        need_grad = c % 7 != 6
+        out = _hip.mll_value_grad_ragged(x.to(dev), y.to(dev), mean.to(dev), nz.to(dev) if use_vec else None, ns.to(dev) if use_scalar else None,
+                                         lengths, w.to(dev), mu.to(dev), v.to(dev), order, 0.0, need_grad)
+        torch.cuda.synchronize()
+        res = {k: t.clone() for k, t in out.items() if torch.is_tensor(t)}
+        assert int(res["info"].abs().max()) == 0, (c, res["info"])
+        set_of, nbs = _hip.ragged_plan(lengths, B)
+        worst = 0.0
+        pick = ri(0, B - 1)
+        for b, n in enumerate(lengths):
+            single = _hip.mll_value_grad(x[b, :n].to(dev), y[b, :n].to(dev), mean[b, :n].to(dev), nz[b, :n].to(dev) if use_vec else None,
+                                         ns[b].to(dev) if use_scalar else None, w[b].to(dev), mu[b].to(dev), v[b].to(dev), order, 0.0, need_grad)
+            torch.cuda.synchronize()
+            assert float(single["mll"]) == float(res["mll"][b]), (c, b, n, float(single["mll"]), float(res["mll"][b]))
+            if need_grad:
+                for p in ("w", "mu", "v"):
+                    a, r = res[f"g_{p}"][b].reshape(-1), single[f"g_{p}"].reshape(-1)
+                    worst = max(worst, float((a - r).abs().max() / (r.abs().max() + 1e-300)))
+                for p in ("noise", "mean"):
+                    a, r = res[f"g_{p}"][b, :n], single[f"g_{p}"].reshape(-1)
+                    worst = max(worst, float((a - r).abs().max() / (r.abs().max() + 1e-300)))
+                    assert float(res[f"g_{p}"][b, n:].abs().sum()) == 0.0
+            if b == pick:
+                total = (nz[b, :n] if use_vec else torch.zeros(n, dtype=D)) + (float(ns[b]) if use_scalar else 0.0)
+                val, gr = orc.mll_value_grad_closed_form(x[b, :n] if d == 2 else x[b, :n, 0], y[b, :n], float(mean[b, 0]), total, w[b], mu[b], v[b], order, 0.0)
+                assert abs(float(val) - float(res["mll"][b])) < 1e-9, (c, b, n)
+                if need_grad:
+                    for p in ("w", "mu", "v"):
+                        a, r = res[f"g_{p}"][b].cpu().reshape(-1), gr[p].reshape(-1).double()
+                        assert float((a - r).abs().max() / (r.abs().max() + 1e-300)) < 1e-7, (c, b, n, p)
+        print(f"ragged case {c}: {B} light curves, lengths {min(lengths)}..{max(lengths)}, q={q} d={d} order={order} "
+              f"noise={'vector' if use_vec else ''}{'+scalar' if use_scalar else ''} grad={need_grad}: sets {nbs}, worst gradient deviation from the singles {worst:.2e}", flush=True)
+        assert worst < 1e-10, (c, worst)
+        _hip.release_workspaces()
