@@ -21,3 +21,39 @@ for rep in range(60):
         elif ref[n] != key: bad += 1; print("MISMATCH", rep, n, ref[n], key)
 torch.cuda.synchronize()
 print(f"{60 * len(sizes)} evaluations over {len(sizes)} alternating sizes in {time.time() - t0:.1f} s, {bad} mismatches against the first result of each size; memory {torch.cuda.memory_allocated() / 2**20:.0f} MiB")
+
+# ragged batches on one workspace, alternating: the length table is re-uploaded and the launch graphs of the trimmed sets are
+# re-captured whenever the lengths change (their class sizes are baked into the grids); every result must repeat bit for bit
+from pgmuvi_amd.batch import evaluate_ragged, pad_curves, ragged_lengths
+batches = []
+for seed, (B, lo, hi) in enumerate([(96, 200, 1500), (40, 100, 900), (96, 300, 1400)]):
+    lens = ragged_lengths(B, lo, hi, seed=seed + 11)
+    curves = []
+    for i, n in enumerate(lens):
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=n)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        curves.append(dict(x=t.double(), y=y.double(), noise=e.double() ** 2, mean=h["mean"], w=h["w"], mu=h["mu"], v=h["v"]))
+    batches.append(pad_curves(curves, device=dev))
+ws = _hip.Workspace(dev, 1500, 4, 1, 96)
+def run(k):
+    p, lens = batches[k]
+    return _hip.mll_value_grad_ragged(p["x"], p["y"], p["mean"], p["noise"], None, lens, p["w"], p["mu"], p["v"], 0, 0.0, True, workspace=ws)
+refs, bad = {}, 0
+for k in range(3):
+    o = run(k); torch.cuda.synchronize()
+    refs[k] = (o["mll"].clone(), o["g_mu"].clone(), o["g_noise"].clone())
+t0 = time.time()
+for rep in range(20): o = run(0)
+torch.cuda.synchronize(); same = (time.time() - t0) / 20 * 1e3
+t0 = time.time()
+for rep in range(20):
+    for k in range(3):
+        o = run(k); torch.cuda.synchronize()
+        if not (torch.equal(o["mll"], refs[k][0]) and torch.equal(o["g_mu"], refs[k][1]) and torch.equal(o["g_noise"], refs[k][2]) and int(o["info"].abs().max()) == 0):
+            bad += 1; print("RAGGED MISMATCH", rep, k)
+alt = (time.time() - t0) / 60 * 1e3
+t0 = time.time()
+for rep in range(20): o = run(0)
+torch.cuda.synchronize(); same2 = (time.time() - t0) / 20 * 1e3
+print(f"ragged: 60 alternating calls of three batches on one workspace, {bad} mismatches; {alt:.2f} ms per call alternating (every call uploads its "
+      f"table and re-captures its launch graphs) against {same:.2f} / {same2:.2f} ms for the first batch repeated")
