@@ -119,12 +119,15 @@ int pgm_mll_value_grad_batched_f64(pgm_ws* ws, int batch,
  *   per-point arrays are padded to a common pitch: x is batch x stride_n x d, y / mean / noise / g_noise / g_mean are
  *   batch x stride_n (entries beyond n_b are neither read nor written); w, mu, v, mll, g_w, g_mu, g_v, info as in
  *   the batched call.
- * The light curves are taken in order of their 128-row block count and advance in launch sets of at most the
- * workspace's max_batch members: a set shares its block-row count, the members that are shorter end in identity
- * padding (which changes no bit of their value: batched == single, bit for bit); lengths join the next longer set
- * where that is cheaper than a launch set of their own (pgm_ragged_plan shows the sets).  The length table is
- * uploaded when it differs from the previous call's (one host synchronisation; none for a fit loop over the same
- * light curves).  Not inside a stream capture (-24).
+ * The light curves are taken in order of their 128-row block count, longest first, and advance in launch sets of at
+ * most the workspace's max_batch members (pgm_ragged_plan shows the sets).  Twelve light curves and more (160 block rows
+ * in all) form ONE set in which every member stops at its own last block row -- no tile beyond it is built, solved,
+ * updated or multiplied; a few light curves run as sets of similar block-row counts whose shorter members end in
+ * identity padding, a length joining the next longer set where that is cheaper than a launch set of its own.  Either
+ * way no bit of a light curve's value depends on the company it is in: batched == single, bit for bit.  The length
+ * table is uploaded when it differs from the previous call's (one host synchronisation, and the launch graphs of
+ * the sets are recorded again; nothing of the kind in a fit loop over the same light curves).  Not inside a stream
+ * capture (-24).
  */
 int pgm_mll_value_grad_ragged_f64(pgm_ws* ws, int batch,
                                   const double* x, const double* y, const double* mean,
