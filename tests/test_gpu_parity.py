@@ -1874,4 +1874,22 @@ def test_performance_guards(dev):
         ms = timed(B, n, 5)
         report.append(f"{B} x N={n}: {ms:.3f} ms (guard {1.5 * ref:.3f})")
         assert ms < 1.5 * ref, f"{B} x N={n}: {ms:.2f} ms per call (measured {ref} ms in round 4, guard {1.5 * ref:.2f} ms)"
+    # ... and the ragged entry point: 64 light curves with N ~ U{1024..2048} as one trimmed launch set (8.2-8.4 ms measured; the
+    # padded sets of round 4's first form take 10.2, the same light curves padded to 2048 points 12.0)
+    from pgmuvi_amd.batch import ragged_lengths
+    lens = ragged_lengths(64, 1024, 2048)
+    padded, lens = pad_curves(_ragged_curves(lens), device=dev)
+    f = lambda: evaluate_ragged(padded=padded, lengths=lens)
+    out = f(); torch.cuda.synchronize()
+    assert int(out["info"].abs().max()) == 0
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 3 * 1e3)
+    _hip.release_workspaces()
+    report.append(f"ragged 64 x N ~ U{{1024..2048}}: {best:.3f} ms (guard {1.2 * 8.4:.3f})")
+    assert best < 1.2 * 8.4, f"ragged 64 x N ~ U{{1024..2048}}: {best:.2f} ms per call (8.4 ms measured; the padded sets take 10.2)"
     print("performance guards: " + "; ".join(report))
