@@ -13,6 +13,14 @@ mkdir -p gpurun_out/prof_ragged512
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ragged512 -o stats -- python3 tools/lab/ragprof.py 512 1024 2048 3 > gpurun_out/prof_ragged512/stats.log 2>&1
 s=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_ragged512/kernel_stats.csv
 k=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_trace.csv' | head -1); python3 tools/timeline.py "$k" > gpurun_out/prof_ragged512/timeline.txt
+d=gpurun_out/prof_ragged512; export PGM_PROFILE_WORKLOAD="python3 tools/lab/ragprof.py 512 1024 2048 3"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d -o fetch -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d -o write -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $d -o tcc -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/tcc.log 2>&1
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $d -o mfma -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/mfma.log 2>&1
+python3 tools/pmc_counter.py "$(find $d -name 'mfma_counter_collection.csv' | head -1)" MfmaUtil > $d/mfma_util.json
+python3 tools/pmc_traffic.py "$(find $d -name 'fetch_counter_collection.csv' | head -1)" "$(find $d -name 'write_counter_collection.csv' | head -1)" $(find $d -name 'tcc_counter_collection.csv' | head -1) > $d/traffic.json
+find $d -name '*_counter_collection.csv' -delete
 find gpurun_out/prof_ragged512 -name '*_kernel_trace.csv' -delete
 mkdir -p gpurun_out/prof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o stats -- python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu > gpurun_out/prof_bench/bench_line.json 2> gpurun_out/prof_bench/bench.err
