@@ -6,6 +6,7 @@
 //   0  v_readlane into scalar registers (rounds 1-3)
 //   1  DPP row_newbcast operands of v_fmac_f64 (same arithmetic, same bits)
 //   2  as 1 with the Newton step folded into the scaling of the row (one dependent instruction less; other rounding)
+//   3 .. 6  timing only: without the Newton step / the 1/sqrt / the rank-4 updates between the mini-panels / the inverse image
 // Prints clock ticks (s_memtime) per factorisation, and the largest difference to variant 0 and to a host factorisation.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -51,17 +52,17 @@ template <int L> __device__ __forceinline__ void fnmac_bcast(double& acc, double
 template <int VAR, int M, int PL>
 __device__ __forceinline__ void pivot(double (&pa)[4], double (&pb)[4]) {
   constexpr int LP = 4 * M + PL;
-  if constexpr (VAR == 0 || VAR >= 3) {
+  if constexpr (VAR == 0 || VAR >= 3) {   // (3 .. 6: timing-only variants of 0)
     const double dp = readlane_d(pa[PL], LP);
     // (timing-only variants: 3 the hardware seed without its Newton step, 4 a multiplication in place of the whole 1/sqrt)
     const double rs = VAR == 3 ? __builtin_amdgcn_rsq(dp) : VAR == 4 ? dp * 0.0625 : rsqrt_nr(dp);
     pa[PL] *= rs;
-    pb[PL] *= rs;
+    if (VAR != 6) pb[PL] *= rs;                     // (6: timing only, the factor without its inverse image -- is the chain bound by issue or by latency?)
 #pragma unroll
     for (int ql = PL + 1; ql < 4; ++ql) {
       const double mult = readlane_d(pa[PL], 4 * M + ql);
       pa[ql] = __builtin_fma(-mult, pa[PL], pa[ql]);
-      pb[ql] = __builtin_fma(-mult, pb[PL], pb[ql]);
+      if (VAR != 6) pb[ql] = __builtin_fma(-mult, pb[PL], pb[ql]);
     }
   } else if constexpr (VAR == 1) {
     const double rs = rsqrt_nr(pa[PL]);           // every lane for its own element; lane LP of each row holds the pivot's
@@ -95,14 +96,14 @@ template <int VAR, int M>
 __device__ __forceinline__ void panel(v4d& ua, v4d& va, double (&fa)[4], double (&fb)[4], int g) {
   double pa[4], pb[4];
   rows_to_all(ua[M], pa);
-  rows_to_all(va[M], pb);
+  if (VAR != 6) rows_to_all(va[M], pb); else { pb[0] = pb[1] = pb[2] = pb[3] = 0.0; }
   pivot<VAR, M, 0>(pa, pb); pivot<VAR, M, 1>(pa, pb); pivot<VAR, M, 2>(pa, pb); pivot<VAR, M, 3>(pa, pb);
   const double ra = (g == 0) ? pa[0] : (g == 1) ? pa[1] : (g == 2) ? pa[2] : pa[3];
   const double rb = (g == 0) ? pb[0] : (g == 1) ? pb[1] : (g == 2) ? pb[2] : pb[3];
   fa[M] = ra; fb[M] = rb;
   if (M < 3 && VAR != 5) {                          // (5: timing only, the pivots without the rank-4 updates between the panels)
     ua = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, ra, ua, 0, 0, 0);
-    va = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, rb, va, 0, 0, 0);
+    if (VAR != 6) va = __builtin_amdgcn_mfma_f64_16x16x4f64(-ra, rb, va, 0, 0, 0);
   }
 }
 
@@ -157,7 +158,7 @@ int main(int argc, char** argv) {
   HIPCHK(hipMalloc((void**)&dA, 256 * 8)); HIPCHK(hipMalloc((void**)&dO, 512 * 8)); HIPCHK(hipMalloc((void**)&dT, 8));
   HIPCHK(hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice));
   std::vector<double> ref(512), got(512);
-  for (int var = 0; var < 6; ++var) {
+  for (int var = 0; var < 7; ++var) {
     long long t = 0;
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     float ms = 0;
@@ -169,6 +170,7 @@ int main(int argc, char** argv) {
       if (var == 3) hipLaunchKernelGGL(k_potrf<3>, dim3(1), dim3(64), 0, 0, dA, dO, dT, iters);
       if (var == 4) hipLaunchKernelGGL(k_potrf<4>, dim3(1), dim3(64), 0, 0, dA, dO, dT, iters);
       if (var == 5) hipLaunchKernelGGL(k_potrf<5>, dim3(1), dim3(64), 0, 0, dA, dO, dT, iters);
+      if (var == 6) hipLaunchKernelGGL(k_potrf<6>, dim3(1), dim3(64), 0, 0, dA, dO, dT, iters);
       HIPCHK(hipEventRecord(e1, 0));
       HIPCHK(hipDeviceSynchronize());
       HIPCHK(hipEventElapsedTime(&ms, e0, e1));
