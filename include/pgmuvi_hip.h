@@ -140,6 +140,9 @@ int pgm_mll_value_grad_ragged_f64(pgm_ws* ws, int batch,
 /* Host only (no GPU): the launch sets of such a call.  set_of_host[b] (batch entries, may be NULL) = the set light curve b
  * runs in, nb_of_set_host[s] (up to batch entries, may be NULL) = the set's block rows; returns the number of sets. */
 int pgm_ragged_plan(const int64_t* n_host, int batch, int max_batch, int* set_of_host, int* nb_of_set_host);
+/* The same for an existing workspace: ITS slot count and the schedule switches frozen when it was made -- exactly the sets
+ * pgm_mll_value_grad_ragged_f64 runs on it (pgm_ragged_plan answers for a workspace that would be made now). */
+int pgm_ragged_plan_ws(pgm_ws* ws, const int64_t* n_host, int batch, int* set_of_host, int* nb_of_set_host);
 
 /*
  * Posterior prediction at n_test inputs from the factor left in the workspace by

@@ -42,6 +42,7 @@ SYMBOLS = {
                                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
     "pgm_ragged_plan": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pgm_ragged_plan_ws": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "pgm_predict_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "pgm_profile_enable": (c_int, [c_void_p, c_int]),
     "pgm_profile_phases": (c_int, []),
@@ -241,10 +242,42 @@ def cached_workspaces(device=None):
         return [w for w in _workspaces.values() if idx is None or w.key[0] == idx]
 
 
+_release_hooks: list = []
+
+
+def on_release(hook):
+    """Registers a callable ``release_workspaces()`` runs: modules that keep Workspace objects of their own outside the cache
+    (``batch._two_streams``' pair) hand them back there."""
+    _release_hooks.append(hook)
+
+
 def release_workspaces():
-    """Empties the cache (buffers are freed as soon as nothing else holds the Workspace objects)."""
+    """Empties the cache -- and the workspaces other modules registered with :func:`on_release` -- (buffers are freed as soon as
+    nothing else holds the Workspace objects)."""
     with _ws_lock:
         _workspaces.clear()
+    for hook in list(_release_hooks):
+        hook()
+
+
+def workspace_bytes_estimate(n: int, q: int, d: int, batch: int) -> int:
+    """Device bytes a workspace for (n, q, d, batch) holds, to first order: the N x N matrix per light curve plus the
+    per-point factors and vectors (``pgm_workspace_create``; the exact figure is ``Workspace.nominal_bytes`` once it exists)."""
+    np_ = (n + 127) // 128 * 128
+    nb = np_ // 128
+    per = 8 * (np_ * np_ + nb * 2 * 128 * 128 + (3 * q * d + d + 40) * np_)
+    return int(batch) * per
+
+
+def trim_cache(reserve_bytes: int = 0):
+    """Drops least-recently-used cache entries until the cache plus ``reserve_bytes`` (workspaces about to be made outside the
+    cache) is within WORKSPACE_BUDGET_BYTES."""
+    with _ws_lock:
+        total = sum(w.nominal_bytes for w in _workspaces.values()) + int(reserve_bytes)
+        for key in list(_workspaces):
+            if total <= WORKSPACE_BUDGET_BYTES:
+                break
+            total -= _workspaces.pop(key).nominal_bytes
 
 
 def current_stream_ptr(device) -> c_void_p:
@@ -376,15 +409,20 @@ def mll_value_grad(x, y, mean, noise, noise_scalar, w, mu, v, dim_order=0, jitte
     return out
 
 
-def ragged_plan(lengths, max_batch: int):
+def ragged_plan(lengths, max_batch: Optional[int] = None, workspace: Optional["Workspace"] = None):
     """The launch sets ``pgm_mll_value_grad_ragged_f64`` forms for these light-curve lengths (host only, no GPU):
-    (set index of every light curve, block rows of every set)."""
+    (set index of every light curve, block rows of every set).  With ``workspace``: the sets THAT workspace runs (its slot
+    count, its schedule switches); otherwise those of a workspace with ``max_batch`` slots made now."""
     import numpy as np
     n = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
     set_of = np.zeros(len(n), dtype=np.int32)
     nb_of = np.zeros(len(n), dtype=np.int32)
-    k = load().pgm_ragged_plan(n.ctypes.data_as(c_void_p), len(n), int(max_batch), set_of.ctypes.data_as(c_void_p),
-                               nb_of.ctypes.data_as(c_void_p))
+    if workspace is not None:
+        k = load().pgm_ragged_plan_ws(workspace.handle, n.ctypes.data_as(c_void_p), len(n), set_of.ctypes.data_as(c_void_p),
+                                      nb_of.ctypes.data_as(c_void_p))
+    else:
+        k = load().pgm_ragged_plan(n.ctypes.data_as(c_void_p), len(n), int(max_batch), set_of.ctypes.data_as(c_void_p),
+                                   nb_of.ctypes.data_as(c_void_p))
     if k < 0:
         raise RuntimeError(f"pgm_ragged_plan failed with status {k}")
     return set_of.tolist(), nb_of[:k].tolist()
@@ -436,6 +474,7 @@ def mll_value_grad_ragged(x, y, mean, noise, noise_scalar, lengths, w, mu, v, di
     out["info"] = info
     out["_keep"] = (xd, yd, md, nz, ns, wd, mud, vd)
     out["workspace"] = ws
+    out["launch_sets"] = ragged_plan(n, workspace=ws)[1]         # (block rows of the sets this call ran: host arithmetic only)
     return out
 
 

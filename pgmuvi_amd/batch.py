@@ -90,12 +90,22 @@ def pad_curves(curves: Sequence[Dict[str, torch.Tensor]], device=None) -> Tuple[
 _twin_workspaces: Dict[tuple, list] = {}
 
 
+def _drop_twins():
+    _twin_workspaces.clear()
+
+
+_hip.on_release(_drop_twins)                                     # (``_hip.release_workspaces()`` gives these back as well)
+
+
 def _two_streams(padded, lengths, dim_order, need_grad, max_batch, streams):
     """Two launch sets at a time: a set of a few dozen light curves leaves CUs idle in the latency-bound links of its sweep (its
     diagonal blocks are one workgroup per member), which another set's updates can use.  The sets (``pgm_ragged_plan``) are
     dealt alternately to two ragged calls, each on a stream and a workspace of its own (512 x N ~ U{1024..2048}: 58.2 -> 54.1 ms
     per pass on one MI355X; the values do not depend on it).  None when there is nothing to overlap (``streams`` None: from
-    four sets on)."""
+    four sets on) -- or when the pair of workspaces does not fit: the caller then runs the sets one after the other.
+
+    ``max_batch`` is the caller's memory bound for ONE workspace (``default_chunk``): each of the two gets half of it, so the
+    pair holds what the one-stream path would."""
     set_of, nbs = _hip.ragged_plan(lengths, max_batch)
     if len(nbs) < (2 if streams == 2 else 4):
         return None
@@ -103,13 +113,21 @@ def _two_streams(padded, lengths, dim_order, need_grad, max_batch, streams):
     halves = [[i for i, s_ in enumerate(set_of) if s_ % 2 == p] for p in (0, 1)]
     B, S = padded["y"].shape
     q, d = padded["w"].shape[-1], padded["x"].shape[-1]
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), (max(lengths) + 127) // 128 * 128, q, d,
-           max(len(h) for h in halves))
-    wss = _twin_workspaces.get(key)
-    if wss is None:
+    slots = max(1, min(max(len(h) for h in halves), (max_batch + 1) // 2))
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), (max(lengths) + 127) // 128 * 128, q, d, slots)
+    if key not in _twin_workspaces:
         _twin_workspaces.clear()                                 # (one pair at a time: the previous batch shape's buffers go)
-        wss = [_hip.Workspace(dev, key[1], q, d, min(key[4], max_batch)) for _ in range(2)]
-        _twin_workspaces[key] = wss + [[torch.cuda.Stream(device=dev) for _ in range(2)]]
+        made = []
+        try:
+            # (the cache's byte budget covers these two as well: what is cached beyond it goes first)
+            _hip.trim_cache(reserve_bytes=2 * _hip.workspace_bytes_estimate(key[1], q, d, slots))
+            for _ in range(2):
+                made.append(_hip.Workspace(dev, key[1], q, d, slots))
+        except RuntimeError:                                     # (no room for the pair: one stream, one workspace)
+            for w in made:
+                w.close()
+            return None
+        _twin_workspaces[key] = made + [[torch.cuda.Stream(device=dev) for _ in range(2)]]
     wss, sts = _twin_workspaces[key][:2], _twin_workspaces[key][2]
     cur = torch.cuda.current_stream(dev)
     parts = []
@@ -132,6 +150,7 @@ def _two_streams(padded, lengths, dim_order, need_grad, max_batch, streams):
             full.index_copy_(0, ix, o[k])
         out[k] = full
     out["_keep"] = parts                                         # (the halves' inputs stay alive until the results have been used)
+    out["launch_sets"] = [nb for _, o in parts for nb in o["launch_sets"]]     # (what the two calls ran, not the plan they were dealt from)
     return out
 
 
@@ -162,6 +181,8 @@ def evaluate_ragged(curves=None, padded: Optional[Dict[str, torch.Tensor]] = Non
         o = compute(padded["x"], padded["y"], padded["mean"], padded.get("noise"), padded.get("noise_scalar"), lengths,
                     padded["w"], padded["mu"], padded["v"], dim_order, 0.0, need_grad, max_batch=max(1, min(chunk, B)))
     out = {"mll": o["mll"], "info": o["info"], "lengths": lengths}
+    if "launch_sets" in o:
+        out["launch_sets"] = list(o["launch_sets"])              # block rows of the launch sets that ran
     if need_grad:
         out.update(g_w=o["g_w"], g_mu=o["g_mu"], g_v=o["g_v"])
         out["g_noise"] = [o["g_noise"][b, :n] for b, n in enumerate(lengths)]

@@ -24,9 +24,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 // polynomial on |r| <= ln2/2 (truncation 4e-18), scaled by 2^n with v_ldexp_f64 (underflows to 0
 // by itself).  19 instructions against ~35 for the library call; every N^2 pass pays one per
 // (pair, mixture, dimension).
-// (No clamp in front: for x far below the underflow threshold n is a large negative number, the conversion to int saturates
-//  and v_ldexp_f64 returns 0 -- the value the clamp to -800 produced, for one instruction less per pair and mixture.)
-__device__ __forceinline__ double exp_neg(double x) {
+// exp_neg_fast: no clamp in front -- for FINITE x far below the underflow threshold n is a large negative number, v_cvt_i32_f64
+// saturates and v_ldexp_f64 returns 0, one instruction less per pair and mixture.  Only for arguments that are finite by
+// construction: -(a - b)^2 of two staged per-point factors in the 1-D build and its gradient epilogue (|a - b| < 1.3e154, i.e.
+// any parameter a constraint admits).  x = -inf would give NaN (inf - inf in the reduction), |x| > 1e45 a garbage reduced
+// argument: everything else goes through exp_neg, which clamps first (-800 is far below the underflow of 2^-1074).
+__device__ __forceinline__ double exp_neg_fast(double x) {
   const double n = rint(x * 1.4426950408889634074);
   double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
   r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
@@ -44,8 +47,10 @@ __device__ __forceinline__ double exp_neg(double x) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return ldexp(p, (int)n);
+  return ldexp(p, (int)n);                                 // (|n| <= ~1155 after the clamp below; without it the conversion saturates in hardware)
 }
+// The general form: exp(-inf) = 0, and so is every finite x below the underflow threshold; the integer conversion stays in range.
+__device__ __forceinline__ double exp_neg(double x) { return exp_neg_fast(fmax(x, -800.0)); }
 
 // idx -> (i <= j) of the column-major enumeration of an upper triangle
 __device__ __forceinline__ void tri_decode(int idx, int& i, int& j) {
@@ -228,8 +233,8 @@ __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* row
         const int m = row0 + rg + 4 * rr;
         const double rc = rq[m], rs = rq[NB + m], rv = rq[2 * NB + m];
         const double d0 = rv - cv0, d1 = rv - cv1;
-        acc[rr][0] = __builtin_fma(exp_neg(-(d0 * d0)), __builtin_fma(rc, cc0, rs * cs0), acc[rr][0]);
-        acc[rr][1] = __builtin_fma(exp_neg(-(d1 * d1)), __builtin_fma(rc, cc1, rs * cs1), acc[rr][1]);
+        acc[rr][0] = __builtin_fma(exp_neg_fast(-(d0 * d0)), __builtin_fma(rc, cc0, rs * cs0), acc[rr][0]);
+        acc[rr][1] = __builtin_fma(exp_neg_fast(-(d1 * d1)), __builtin_fma(rc, cc1, rs * cs1), acc[rr][1]);
       }
     }
 #pragma unroll
@@ -1719,7 +1724,7 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const double ds = rv[r] - cv;
-              const double GE = acc[ti][tj][r] * exp_neg(-(ds * ds));
+              const double GE = acc[ti][tj][r] * exp_neg_fast(-(ds * ds));
               const double CC = __builtin_fma(rc[r], cc_, rs[r] * cs_);
               const double SN = __builtin_fma(rs[r], cc_, -(rc[r] * cs_));
               const double tau = rx[r] - cx;

@@ -9,10 +9,8 @@ children of the same command line -- one per rank, with ``RANK`` / ``LOCAL_RANK`
 has initialised the GPU is ever replaced by another program (that takes the whole
 machine down on this pool): children are started with ``subprocess.Popen``.
 
-Nothing here imports torch; the caller passes the number of visible devices.  (``bench.py`` counts them with
-``torch.cuda.device_count()``, which on ROCm may open the HIP runtime in the parent; that was only verified to be harmless
-here -- the parent never launches GPU work and only ever starts fresh children, and the one-rank spawn path is green on
-the GPU box -- not to leave the runtime untouched.)
+Nothing here imports torch.  The parent counts the GPUs without the HIP runtime (:func:`visible_gpu_count`: the kernel
+driver's topology files and the ``*_VISIBLE_DEVICES`` variables), so it never opens the device it then hands to its children.
 """
 from __future__ import annotations
 
@@ -32,6 +30,50 @@ def under_a_launcher(env=None) -> bool:
     """Has somebody (torch.distributed.run, or :func:`spawn_ranks`) already made this process one rank of a job?"""
     env = os.environ if env is None else env
     return "WORLD_SIZE" in env and "RANK" in env
+
+
+def _kfd_gpu_nodes(root: str = "/sys/class/kfd/kfd/topology/nodes", dri: str = "/dev/dri") -> Optional[int]:
+    """GPUs the kernel driver lists and this process may open: topology nodes with ``simd_count`` > 0 (CPU nodes have 0) whose
+    render node ``/dev/dri/renderD<drm_render_minor>`` is readable and writable (a container that was given one GPU of eight
+    still sees all eight in the topology).  None when the files are not there (no amdgpu driver, or a sandbox that hides /sys)."""
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    count = 0
+    for node in nodes:
+        props = {}
+        try:
+            with open(os.path.join(root, node, "properties")) as fh:
+                for line in fh:
+                    key, _, val = line.partition(" ")
+                    if key in ("simd_count", "drm_render_minor"):
+                        props[key] = int(val)
+        except (OSError, ValueError):
+            continue                                           # (a node this user may not read is not a device it may use)
+        if props.get("simd_count", 0) <= 0:
+            continue
+        minor = props.get("drm_render_minor", -1)
+        if minor > 0 and os.path.isdir(dri) and not os.access(os.path.join(dri, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
+        count += 1
+    return count
+
+
+def visible_gpu_count(env=None, kfd_root: str = "/sys/class/kfd/kfd/topology/nodes") -> Optional[int]:
+    """How many GPUs a child of this process would see -- WITHOUT touching the HIP runtime: the driver's topology count, cut
+    down by ``ROCR_VISIBLE_DEVICES`` / ``HIP_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` (comma lists; an empty value hides
+    every device) as the runtime would apply them.  None: unknown (no topology files) -- the caller then skips its check and
+    lets the ranks report what they find."""
+    env = os.environ if env is None else env
+    total = _kfd_gpu_nodes(kfd_root)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in env:
+            listed = [t for t in env[var].split(",") if t.strip() != ""]
+            if any(t.strip() == "-1" for t in listed):          # (the runtime stops at the first -1)
+                listed = listed[:[t.strip() for t in listed].index("-1")]
+            total = len(listed) if total is None else min(total, len(listed))
+    return total
 
 
 def free_port() -> int:
@@ -84,8 +126,10 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
     # a driver that ends the parent on a time-out must not leave N processes holding GPUs: the parent passes SIGTERM / SIGINT
     # on to its children and leaves through the ``finally`` below (only in the main thread: signal handlers live there)
     previous = {}
+    caught = []
 
     def on_signal(signum, frame):
+        caught.append(signum)
         stop_children(signal.SIGTERM)
         raise KeyboardInterrupt(f"launch: signal {signum}")
 
@@ -131,8 +175,26 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
         reader.join(timeout=10)
         return status if status >= 0 else 128 - status             # (killed by a signal: the shell's convention)
     except KeyboardInterrupt:
-        return 130
+        # the children got SIGTERM from the handler (or the terminal's SIGINT themselves): give them ``grace_s`` to leave their
+        # kernels and tear RCCL down before the ``finally`` below kills what is left; 128 + signal as a shell reports it
+        interrupted = 128 + (caught[-1] if caught else signal.SIGINT)
+        for sg in previous:                                    # (a second signal must not break the cleanup off)
+            try:
+                signal.signal(sg, signal.SIG_IGN)
+            except (OSError, ValueError):
+                pass
+        if not caught:
+            stop_children(signal.SIGTERM)
+        deadline = time.monotonic() + grace_s
+        while time.monotonic() < deadline and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+        return interrupted
     finally:
+        for sg in previous:
+            try:
+                signal.signal(sg, signal.SIG_IGN)
+            except (OSError, ValueError):
+                pass
         for p in procs:
             if p.poll() is None:
                 p.kill()

@@ -32,11 +32,15 @@ def _failed(out) -> bool:
 class _Deferred(threading.local):
     """Evaluations whose factorisation status nobody has asked for yet (``settings.defer_cholesky_check``): per thread -- a
     second thread's training loop must not collect this one's -- and bounded, so that a caller who switches the flag on and
-    never asks does not pin every evaluation's workspace and gradient buffers (the oldest entries are simply forgotten)."""
+    never asks does not pin every evaluation's workspace and gradient buffers.  An entry that has to leave is asked for its
+    status first (its own ``info``, read from the device: the workspace's stamp may belong to a later evaluation by then) and a
+    failure stays behind as a sticky flag, so an LBFGS closure with a line search, or several models per iteration, cannot
+    lose a failed factorisation by running more than LIMIT evaluations between two queries."""
     LIMIT = 8
 
     def __init__(self):
         self.items = []
+        self.evicted_failure = False
 
 
 _deferred = _Deferred()
@@ -44,20 +48,22 @@ _deferred = _Deferred()
 
 def _defer(out):
     _deferred.items.append(out)
-    if len(_deferred.items) > _Deferred.LIMIT:
-        del _deferred.items[: len(_deferred.items) - _Deferred.LIMIT]
+    while len(_deferred.items) > _Deferred.LIMIT:
+        old = _deferred.items.pop(0)
+        _deferred.evicted_failure = _failed(old) or _deferred.evicted_failure
 
 
 def drop_deferred():
     """Forget the pending evaluations (a loop's ``finally``: an exception between the evaluation and the status query)."""
     _deferred.items.clear()
+    _deferred.evicted_failure = False
 
 
 def take_deferred_failure() -> bool:
     """Did any evaluation run under ``settings.defer_cholesky_check`` since the last call (on this thread) fail to factor?
     Waits for the factorisation sweep of those evaluations only (by the time a training loop asks -- after
     ``loss.backward()`` -- it is usually over)."""
-    failed = False
+    failed, _deferred.evicted_failure = _deferred.evicted_failure, False
     items, _deferred.items = _deferred.items, []
     for out in items:
         failed = _failed(out) or failed

@@ -1133,6 +1133,28 @@ def test_generic_kernel_programs_vs_oracle(dev, d):
     assert int(bad["info"]) > 0 and torch.isnan(bad["mll"]) and torch.isnan(bad["g_theta"]).all()
 
 
+def test_generic_kernel_with_an_underflowing_lengthscale(dev):
+    """A length scale so small that the scaled squared distance overflows (u = inf): every off-diagonal entry of the kernel
+    matrix is exp(-inf) = 0 -- not NaN -- and the evaluation is that of a diagonal matrix (the unclamped exp is
+    for the 1-D spectral-mixture passes only, whose argument is finite by construction)."""
+    from pgmuvi_amd.gpytorch import kernels as K
+    from pgmuvi_amd.gpytorch.kernels import compile_program
+    for base in (K.RBFKernel(), K.MaternKernel(nu=1.5), K.RQKernel()):
+        base.lengthscale = 1e-170
+        sk = K.ScaleKernel(base); sk.outputscale = 0.8
+        prog = compile_program(sk.double(), 1)
+        theta = prog.theta().detach()
+        n = 300
+        gen = torch.Generator().manual_seed(7)
+        x = torch.sort(torch.rand(n, 1, generator=gen, dtype=D) * 300.0, dim=0).values
+        y = torch.randn(n, generator=gen, dtype=D)
+        nz = 0.02 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+        out = _hip.mll_kernel_value_grad(x.to(dev), y.to(dev), torch.zeros(n, dtype=D, device=dev), nz.to(dev), None, prog, theta.to(dev))
+        diag = 0.8 + nz
+        want = -0.5 * (float((y * y / diag).sum()) + float(torch.log(diag).sum()) + n * np.log(2 * np.pi)) / n
+        assert int(out["info"]) == 0 and abs(float(out["mll"]) - want) < 1e-9, (type(base).__name__, float(out["mll"]), want)
+
+
 def test_generic_kernel_models_through_the_surface(dev):
     """``model(x) -> mll -> backward`` of the reference's quasi-periodic and separable model shapes on the fused generic path:
     loss and every raw-parameter gradient equal the same model evaluated through the dense back-end (the matrix built by

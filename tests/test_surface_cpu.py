@@ -270,3 +270,62 @@ def test_train_picks_the_fused_optimiser_step_only_for_gpu_parameters():
     p.grad = torch.ones(3, dtype=torch.float64)
     opt.step()
     assert float(p[0]) < 0.0
+
+
+def test_launcher_counts_gpus_without_the_hip_runtime(tmp_path):
+    """``launch.visible_gpu_count``: topology nodes with SIMDs whose render node this process may open, cut down by the
+    *_VISIBLE_DEVICES lists -- no torch, no HIP call in the parent of ``bench.py --gpus N``."""
+    from pgmuvi_amd import launch
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    for i, (simd, minor) in enumerate([(0, -1), (1024, 128), (1024, 129), (1024, 130)]):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    dri.mkdir()
+    for m in (128, 129):
+        (dri / f"renderD{m}").write_text("")
+    assert launch._kfd_gpu_nodes(str(nodes), str(dri)) == 2                       # (renderD130 is not ours)
+    assert launch._kfd_gpu_nodes(str(nodes), str(tmp_path / "none")) == 3         # (no /dev/dri to check against)
+    assert launch._kfd_gpu_nodes(str(tmp_path / "missing")) is None
+    assert launch.visible_gpu_count({}, str(tmp_path / "missing")) is None
+    assert launch.visible_gpu_count({"HIP_VISIBLE_DEVICES": "0,2"}, str(tmp_path / "missing")) == 2
+    assert launch.visible_gpu_count({"HIP_VISIBLE_DEVICES": ""}, str(tmp_path / "missing")) == 0
+    assert launch.visible_gpu_count({"ROCR_VISIBLE_DEVICES": "0,1,2", "HIP_VISIBLE_DEVICES": "1"}, str(tmp_path / "missing")) == 1
+    assert launch.visible_gpu_count({"CUDA_VISIBLE_DEVICES": "0,-1,2"}, str(tmp_path / "missing")) == 1
+    import ast, inspect
+    imported = {a.name.split(".")[0] for node in ast.walk(ast.parse(inspect.getsource(launch))) if isinstance(node, (ast.Import, ast.ImportFrom))
+                for a in (node.names if isinstance(node, ast.Import) else [ast.alias(name=node.module or "")])}
+    assert "torch" not in imported
+
+
+def test_deferred_check_keeps_a_failure_that_had_to_leave():
+    """``settings.defer_cholesky_check``: more than LIMIT evaluations between two queries (an LBFGS closure with a line search)
+    must not lose a failed factorisation among the evicted ones."""
+    from pgmuvi_amd import mll_function as mf
+    mf.drop_deferred()
+    ok = {"info": torch.zeros(1, dtype=torch.int32)}
+    bad = {"info": torch.tensor([3], dtype=torch.int32)}
+    mf._defer(bad)
+    for _ in range(mf._Deferred.LIMIT + 3):
+        mf._defer(dict(ok))
+    assert len(mf._deferred.items) == mf._Deferred.LIMIT
+    assert mf.take_deferred_failure() is True
+    assert mf.take_deferred_failure() is False                # (the flag is consumed with the query)
+    for _ in range(mf._Deferred.LIMIT + 3):
+        mf._defer(dict(ok))
+    assert mf.take_deferred_failure() is False
+    mf._defer(bad)
+    for _ in range(mf._Deferred.LIMIT + 1):
+        mf._defer(dict(ok))
+    mf.drop_deferred()
+    assert mf.take_deferred_failure() is False
+
+
+def test_release_workspaces_reaches_the_workspaces_outside_the_cache():
+    """``batch._two_streams`` keeps a pair of workspaces of its own; ``_hip.release_workspaces()`` hands them back too, and
+    their bytes are weighed against the cache budget when they are made."""
+    from pgmuvi_amd import _hip, batch
+    batch._twin_workspaces[("fake",)] = [object(), object(), []]
+    _hip.release_workspaces()
+    assert not batch._twin_workspaces
+    est = _hip.workspace_bytes_estimate(2048, 4, 1, 3)
+    assert 3 * 8 * 2048 * 2048 <= est <= 3 * 8 * 2048 * 2048 * 1.2
