@@ -98,8 +98,9 @@ def cpu_baseline(n, reps, recipe="cfg2", threads=None, budget_s=None):
     """The oracle (torch-CPU restatement of the reference path, NOT GPyTorch) timed on the
     host cores: value + gradient by autograd through the dense graph, as loss.backward()
     does in the reference.  Median of ``reps`` (>= 5) after one warm-up.
-    ``threads``: torch threads (default: one GPU's share of the host, at most 16); ``budget_s``: stop repeating once that many
-    seconds have gone into the timed repetitions, but never before three of them (the count is in ``sample``)."""
+    ``threads``: torch threads (default: one GPU's share of the host, at most 16); ``budget_s``: a time limit for the whole
+    measurement -- repetitions stop once it is used up (never before three), and when the warm-up evaluation alone takes more
+    than half of it that evaluation is the sample (counts and warm-ups are in ``sample``)."""
     from oracle import sm_mll_oracle as orc
     capped = threads is None
     torch.set_num_threads(_host_threads() if capped else max(1, int(threads)))
@@ -113,23 +114,45 @@ def cpu_baseline(n, reps, recipe="cfg2", threads=None, budget_s=None):
         what = f"light curve 0 of the batch (N={n}, Q=4)"
     x64, y64, nz = t.double(), y.double(), e.double() ** 2
     mu, v = h["mu"].reshape(-1, 1), h["v"].reshape(-1, 1)
-    orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)      # warm-up
     times = []
     val = None
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        val, _g = orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)
-        times.append(time.perf_counter() - t0)
-        if budget_s is not None and len(times) >= 3 and sum(times) > budget_s:
-            break
+    t0 = time.perf_counter()
+    val, _g = orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)      # warm-up
+    first = time.perf_counter() - t0
+    if budget_s is not None and first > budget_s / 2:
+        times.append(first)                                  # (no room for more within the budget: the warm-up IS the sample)
+    else:
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            val, _g = orc.mll_value_grad_autograd(x64, y64, h["mean"], nz, h["w"], mu, v)
+            times.append(time.perf_counter() - t0)
+            if budget_s is not None and len(times) >= 3 and first + sum(times) > budget_s:
+                break
     done = len(times)
+    warm = 0 if (budget_s is not None and first > budget_s / 2) else 1
     times.sort()
     med = times[len(times) // 2]
     how = ("torch threads capped at 16 = one GPU's share of the host" if capped else
-           f"torch.set_num_threads({torch.get_num_threads()}): BASELINE.md section 2's protocol, every logical CPU this process may use")
+           f"torch.set_num_threads({torch.get_num_threads()}): BASELINE.md section 2's protocol, every logical CPU this process may be scheduled on"
+           f" (CPU quota of the box's cgroup: {_cpu_quota()})")
     return dict(value=1.0 / med, unit="evals/s", cores=torch.get_num_threads(), kind="port", cpu_model=_cpu_model(),
-                sample=f"{done} value+grad evaluations (1 warm-up) of {what}, median {med * 1e3:.0f} ms; torch-CPU restatement of the "
+                sample=f"{done} value+grad evaluation(s) ({warm} warm-up) of {what}, median {med * 1e3:.0f} ms; torch-CPU restatement of the "
                        f"reference path (oracle/), not GPyTorch; {how} ({os.cpu_count()} logical CPUs on the box)"), float(val)
+
+
+def _cpu_quota():
+    """CPUs' worth of time the cgroup grants this process ("16.0 CPUs"), or "none"."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                return "none" if txt[0] == "max" else f"{int(txt[0]) / int(txt[1]):.1f} CPUs"
+            q = int(txt[0])
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return "none" if q < 0 else f"{q / per:.1f} CPUs"
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return "unknown"
 
 
 def _all_cores():
@@ -581,7 +604,7 @@ def main():
         # BASELINE.md section 2 / SURVEY.md section 8d word the protocol with torch.set_num_threads(os.cpu_count()): that figure
         # beside the 16-thread one (`cpu_baseline` stays the one-GPU share of the host, as in every earlier round's record)
         if _all_cores() != cb["cores"]:
-            cb_all, val_all = cpu_baseline(n, args.cpu_reps, threads=_all_cores(), budget_s=12.0)
+            cb_all, val_all = cpu_baseline(n, args.cpu_reps, threads=_all_cores(), budget_s=14.0)
             cb_all["abs_dmll_vs_16_thread_run"] = abs(val_all - cpu_val)
             result["cpu_baseline_all_cores"] = cb_all
             result["speedup_vs_cpu_baseline_all_cores"] = round(value / cb_all["value"], 1)

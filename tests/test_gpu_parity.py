@@ -1140,10 +1140,11 @@ def test_generic_kernel_with_an_underflowing_lengthscale(dev):
     from pgmuvi_amd.gpytorch import kernels as K
     from pgmuvi_amd.gpytorch.kernels import compile_program
     for base in (K.RBFKernel(), K.MaternKernel(nu=1.5), K.RQKernel()):
-        base.lengthscale = 1e-170
-        sk = K.ScaleKernel(base); sk.outputscale = 0.8
-        prog = compile_program(sk.double(), 1)
-        theta = prog.theta().detach()
+        sk = K.ScaleKernel(base.double()).double(); sk.outputscale = 0.8
+        prog = compile_program(sk, 1)
+        theta = prog.theta().detach().clone()
+        theta[0] = 1e-160          # the length scale, straight into the parameter vector (the softplus of the surface cannot produce it)
+        theta[-1] = 0.8
         n = 300
         gen = torch.Generator().manual_seed(7)
         x = torch.sort(torch.rand(n, 1, generator=gen, dtype=D) * 300.0, dim=0).values
