@@ -170,8 +170,6 @@ int pgm_profile_read(pgm_ws* ws, double* ms_host, int64_t* launches_host);
  * factorisation sweep's diagonal-block launches (on CUs those launches would leave idle) instead of in the
  * inverse/gradient launch; 0 when that does not apply (batches, small or very large N).  For flop accounting. */
 int64_t pgm_profile_early_inverse_products(const pgm_ws* ws);
-/* ... and in the waves of the side queue that runs beside the chain's late block rows (PGM_SIDE_CUS; 0 when it is off) */
-int64_t pgm_profile_side_inverse_products(const pgm_ws* ws);
 
 /*
  * Device-resident fit: the optimiser loop of pgmuvi/trainers.py:177-195 for a

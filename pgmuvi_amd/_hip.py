@@ -49,7 +49,6 @@ SYMBOLS = {
     "pgm_profile_phase_name": (c_char_p, [c_int]),
     "pgm_profile_read": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     "pgm_profile_early_inverse_products": (c_int64, [c_void_p]),
-    "pgm_profile_side_inverse_products": (c_int64, [c_void_p]),
     "pgm_probe_mfma_f64": (c_int, [c_int, POINTER(c_double)]),
     "pgm_mll_dense_f64": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_void_p]),
@@ -188,10 +187,6 @@ class Workspace:
     def early_inverse_products(self) -> int:
         """128^3 products of the inverse pass the last single-curve evaluation ran inside the sweep's launches."""
         return int(load().pgm_profile_early_inverse_products(self.handle))
-
-    def side_inverse_products(self) -> int:
-        """128^3 products of the inverse pass the last single-curve evaluation ran on the side queue beside the chain."""
-        return int(load().pgm_profile_side_inverse_products(self.handle))
 
 
 # Cache of workspaces, least recently used first.  A request is served by ANY cached workspace that covers it (the C side

@@ -92,13 +92,10 @@ struct PgmDev {
   int build_beside;   // 1: k_build builds block row 0 only, the rest of the matrix is built by the spare workgroups of diagonal block 0's launch
   int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups)
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
-  int side_from;      // > 0 (host-side planning only): from this block row on the chain shares the chip with the side queue of the
-                      //   inverse pass (pgm_ws::side_*): its launches are planned for 256 - side_cus CUs, and the tiles (i, j) of
-                      //   R with j < side_from belong to the side queue's work items
   KProg prog;
 };
 
-enum PgmPhase { PH_PRE = 0, PH_BUILD, PH_DIAG, PH_TRSM, PH_UPDATE, PH_LAUUM, PH_FINAL, PH_FUSED, PH_SIDE, PH_COUNT };
+enum PgmPhase { PH_PRE = 0, PH_BUILD, PH_DIAG, PH_TRSM, PH_UPDATE, PH_LAUUM, PH_FINAL, PH_FUSED, PH_COUNT };
 
 struct pgm_ws {
   int device;
@@ -154,24 +151,6 @@ struct pgm_ws {
   int4* early_items;     // device copy
   int early_cap, early_final_n;
   double* Rbuf; size_t R_bytes;
-  // Side queue of the inverse pass (one light curve, plain fused sweep, direct launches): from block row
-  // side_from on, a second stream confined to side_cus CUs (hipExtStreamCreateWithCUMask) sums products of block rows that are
-  // final into R -- work items (i, j, p0, k-blocks) over the tiles j < side_from, in waves: wave w is enqueued behind the row
-  // solve of block row side_after[w] (one event) -- while the chain runs on on the other CUs; the final inverse/gradient launch
-  // waits for the queue (one event) and continues from R.
-  int side_cus;          // PGM_SIDE_CUS: CUs of the side queue (0: off)
-  int side_row;          // PGM_SIDE_ROW: first block row of the chain that runs beside it (-1: 5/8 of the block rows)
-  int side_step;         // PGM_SIDE_STEP: block rows between two waves
-  int side_waves;        // PGM_SIDE_WAVES: waves at most
-  int side_kc;           // PGM_SIDE_KC: k-blocks per work item at most (a tile's backlog beyond it waits for the next wave)
-  int side_budget;       // PGM_SIDE_BUDGET: products per wave at most (0: every tile that is behind), the tiles furthest behind first
-  hipStream_t side_stream; int side_stream_cus;
-  hipEvent_t side_fork[8], side_join; bool side_events;
-  int early_side;        // side_from the tables below were made for (0: without the side queue)
-  int side_first;        // the side queue's work items start here in early_host / early_items (behind the filler tasks)
-  std::vector<int4> side_host;           // (while a plan is being made)
-  std::vector<int> side_after, side_lo, side_n;   // wave w: behind row solve side_after[w], items [side_lo[w], +side_n[w]) of the side part
-  int64_t side_products; // 128^3 products per evaluation in the side queue's waves (profiling)
   // hipGraph replay of the launch sequence behind k_precompute
   bool use_graph;
   hipStream_t cap_stream;

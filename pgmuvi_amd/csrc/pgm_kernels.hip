@@ -1986,35 +1986,6 @@ __global__ __launch_bounds__(256, 2) void k_lauum_grad_rag(PgmDev P, RagClasses 
   lauum_grad_item<D, ORDER, C>(P, lds, b, bx, rows);
 }
 
-// The inverse pass BESIDE the chain (the side queue: pgm_internal.h).  One work item = the products of block
-// rows p0 .. p0 + len - 1 of tile (i <= j) of A^-1 = V^T V, summed into R -- negated, like the early products of the sweep's
-// filler workgroups (early_inverse_tile), so that whoever continues the tile (a later wave, the final k_lauum_grad launch) reads
-// it back the same way.  Launched on a stream of its own, confined to a subset of the CUs, behind an event of the row solve that
-// made its last block row final; the tiles of a launch are distinct.  k-depth len * 128: the C tile's round trip is paid once
-// per item, not once per product as in the fillers of the chain's launches.
-template <class C>
-__global__ __launch_bounds__(256, 2) void k_inverse_side(PgmDev P, const int4* __restrict__ items) {
-  static_assert(C::DIRECT && C::NT == NTHREADS, "the direct loop: no LDS");
-  const int4 item = items[blockIdx.x];
-  const int i = item.x, j = item.y, p0 = item.z, len = item.w & 0xffff;
-  const bool cont = (item.w & LAUUM_LOAD) != 0;
-  const int64_t ld = P.ld;
-  const double* A = P.A;
-  const double* Dv = P.Dinv;
-  double* Rp = P.R + (int64_t)i * NB * ld + j * NB;
-  auto operands = [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
-    const int p = p0 + kb;
-    if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB; lda = ld; }
-    else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB; lda = NB; }
-    if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB; ldb = ld; }
-    else { pb = Dv + ((int64_t)j * 2 + 1) * NB * NB; ldb = NB; }
-  };
-  v4d acc[C::TM][C::TN];
-  if (cont) acc_load_raw<C, FILL_NT>(Rp, ld, acc); else acc_zero<C>(acc);
-  gemm_tn<C>(nullptr, len, operands, acc, 0, cont);
-  acc_store<C, FILL_NT>(Rp, ld, acc, -1.0);
-}
-
 // ---------------------------------------------------------------------------
 // Generic dense K(x1, x2) for to_dense() / cross-covariances (not on the MLL path).
 // ---------------------------------------------------------------------------
