@@ -1297,6 +1297,186 @@ __global__ __launch_bounds__(T16_THREADS) void k_trsm16(PgmDev P, int k, int nsl
 }
 
 // ---------------------------------------------------------------------------
+// The chain's row solve for a HANDFUL of light curves in the fused sweep (round 5; config 5's tick: 8 chains x N=2048).
+// k_trsm16 gives every 128 x 32 slab a workgroup that holds a whole CU: with eight light curves a block row is 8 x (60 slabs +
+// 36 look-ahead pairs) = 768 of them, three rounds -- and the staged slab kernel (k_trsm, two per CU) pays its eight chunk
+// latencies in 1.5 rounds: 24 us per block row either way, on a chain of 16 (`profiles/r04_timeline_cfg5_tick_8x2048.txt`).
+// Here a workgroup takes a 128 x 64 slab -- or, `npass` = 2, the two slabs of a block one after the other, the triangle of
+// U_kk^-1 staying in LDS and the second slab's values already on their way while the first is solved -- and every wavefront
+// (rb, h) runs TWO 16 x 16 blocks side by side: the dependent v_mfma_f64_16x16x4 chain of k_trsm16 advances a step per ~135
+// cycles where the pipe issues one per 64, so the second block rides in the shadow of the first.  The look-ahead, 36 workgroups
+// per light curve there, is 6 here: two for the diagonal quadrants of the next diagonal tile (the 64 columns of its half
+// solved from the copy in P.crit, then the quadrant's upper 16 x 16 blocks, one per wavefront, 32 k-steps in order from -C) and
+// four for the quadrant above the diagonal (32 columns of either half, 2 x 2 blocks each).  8 x N=2048: 8 x (15 + 6) = 168
+// workgroups, one round.  Every 16 x 16 block of the solve still receives its k-steps in ascending order from zero, every
+// block of the next diagonal tile its 32 from -C, and the forward-substitution sums are formed in the slab kernel's order:
+// the bits of k_trsm and k_trsm16 (PGM_TRSM64=0; tests compare).  The update sub-tiles that k_trsm carries in its grid's tail
+// do not ride here (every workgroup of this kernel holds a CU): the host launches them behind it (k_update_rows).
+// ---------------------------------------------------------------------------
+constexpr int T64_LOOK = 6;                                    // look-ahead workgroups per light curve
+constexpr int T64_B = 4 * T16_HALF;                            // the slab's image: four 16-column blocks [row][16], unsolved, then solved in place
+static_assert(T16_PANEL + T64_B == T16_LDS, "k_trsm16's LDS budget");
+
+// the 128 x 64 slab whose two 32-column groups start at columns co0 / co1 of Cs: 16-byte pieces, four per thread
+__device__ __forceinline__ void slab64_load(const double* __restrict__ Cs, int64_t ldc, int co0, int co1, v2d (&bt)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = (int)threadIdx.x + u * T16_THREADS, row = e >> 5, c2 = (e & 31) * 2;
+    bt[u] = *reinterpret_cast<const v2d*>(Cs + (int64_t)row * ldc + (c2 < 32 ? co0 + c2 : co1 + c2 - 32));
+  }
+}
+__device__ __forceinline__ void slab64_put(double* __restrict__ Bs, const v2d (&bt)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = (int)threadIdx.x + u * T16_THREADS, row = e >> 5, c2 = (e & 31) * 2;
+    *reinterpret_cast<v2d*>(Bs + (c2 >> 4) * T16_HALF + row * 16 + (c2 & 15)) = bt[u];
+  }
+}
+// wavefront (rb, h): the two 16 x 16 blocks of rows 16 rb .. of column blocks 2 h and 2 h + 1, 4 (rb + 1) k-steps each in order
+// from zero (A fragments: panel rb of U_kk^-1; B fragments: the unsolved image), fragments one group of four ahead
+__device__ __forceinline__ void solve64_blocks(const double* __restrict__ pan, const double* __restrict__ Bs, int rb, int h, int g, int n,
+                                               v4d& acc0, v4d& acc1) {
+  acc0 = v4d{0.0, 0.0, 0.0, 0.0}; acc1 = acc0;
+  const double* pa = pan + t16_panel(rb) + g * 16 + n;
+  const double* pb = Bs + 2 * h * T16_HALF + g * 16 + n;
+  double a[4], b0[4], b1[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { a[u] = pa[u * 64]; b0[u] = pb[u * 64]; b1[u] = pb[T16_HALF + u * 64]; }
+#pragma clang loop unroll(disable)
+  for (int gq = 0; gq <= rb; ++gq) {
+    double an[4], bn0[4], bn1[4];
+    const int nx = (gq < rb) ? gq + 1 : gq;                    // (the last group reads its own fragments again: no branch in the loop)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { an[u] = pa[(4 * nx + u) * 64]; bn0[u] = pb[(4 * nx + u) * 64]; bn1[u] = pb[T16_HALF + (4 * nx + u) * 64]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b0[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b1[u], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = an[u]; b0[u] = bn0[u]; b1[u] = bn1[u]; }
+  }
+}
+
+__global__ __launch_bounds__(T16_THREADS) void k_trsm64(PgmDev P, int k, int nitems, int npass, int nlook) {
+  __shared__ __attribute__((aligned(16))) double pan[T16_LDS];
+  __shared__ double zs[NB];
+  __shared__ double red[4][64];
+  double* Bs = pan + T16_PANEL;
+  const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int rb = t16_rb(wave), h = wave >> 3;
+  const int g = lane >> 4, n = lane & 15;
+  const double* Uinv = P.Dinv + b * P.sDinv + (int64_t)k * 2 * NB * NB;
+  const bool look = (int)blockIdx.x < nlook;                   // (uniform)
+  // ---- what this workgroup solves: `passes` slabs of 64 columns, the first one's two 32-column groups at co0 / co1 of Cs
+  const double* Cs; int64_t ldc; int co0, co1, passes = 1, jb = 0, half0 = 0;
+  int role = 0;
+  if (look) {
+    role = (int)blockIdx.x;                                    // 0, 1: diagonal quadrants; 2 .. 5: the quadrant above the diagonal, 32 x 32 columns each
+    Cs = P.crit + (int64_t)b * NB * NB; ldc = NB;
+    if (role < 2) { co0 = 64 * role; co1 = co0 + 32; }
+    else { co0 = 32 * ((role - 2) >> 1); co1 = 64 + 32 * ((role - 2) & 1); }
+  } else {
+    const int item = (int)blockIdx.x - nlook;
+    if (item >= nitems) return;
+    int jbi = (npass == 2) ? item : item >> 1;
+    half0 = (npass == 2) ? 0 : (item & 1);
+    passes = npass;
+    if (P.need_grad) { if (jbi >= k) jbi += 1; } else { jbi += k + 1; }
+    jb = jbi;
+    Cs = P.A + b * P.sA + (int64_t)k * NB * P.ld + jb * NB; ldc = P.ld;
+    co0 = 64 * half0; co1 = co0 + 32;
+    if (t < NB) zs[t] = P.z[b * P.sVec + k * NB + t];
+  }
+  // ---- every global load of the workgroup at once: the slab, the panels of U_kk^-1 (and, look-ahead, the blocks it will update)
+  v2d bt[4];
+  slab64_load(Cs, ldc, co0, co1, bt);
+  {
+    v2d ut[8];
+    const int prow = t >> 3, pc2 = (t & 7) * 2;               // panel q: thread t < 128 (q + 1) takes piece (row t / 8, columns 2 (t % 8) ..)
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (t < 128 * (q + 1)) ut[q] = *reinterpret_cast<const v2d*>(Uinv + prow * NB + 16 * q + pc2);
+    slab64_put(Bs, bt);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (t < 128 * (q + 1)) *reinterpret_cast<v2d*>(pan + t16_panel(q) + prow * 16 + pc2) = ut[q];
+  }
+  // look-ahead: wavefront w owns block (bi, bj) of its quadrant -- global 16-column block indices (gi, gj) of the next diagonal tile
+  int bi = 0, bj = 0, gi = 0, gj = 0;
+  bool mine = false;
+  v4d d = {0.0, 0.0, 0.0, 0.0};
+  double* Cd = nullptr;
+  if (look) {
+    if (role < 2) { bi = wave >> 2; bj = wave & 3; mine = bi <= bj; gi = 4 * role + bi; gj = 4 * role + bj; }
+    else { bi = wave >> 1; bj = 2 + (wave & 1); mine = wave < 4; gi = 2 * ((role - 2) >> 1) + bi; gj = 4 + 2 * ((role - 2) & 1) + (bj - 2); }
+    if (mine) {                                                // (final since the launch before: its round trip rides with the others)
+      Cd = P.A + b * P.sA + ((int64_t)(k + 1) * NB + gi * 16 + g) * P.ld + (k + 1) * NB + gj * 16 + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r] = Cd[(int64_t)4 * r * P.ld];
+    }
+  }
+  for (int pass = 0; pass < passes; ++pass) {
+    __syncthreads();                                            // the operands are in LDS
+    const bool more = pass + 1 < passes;                        // (uniform) the next slab's values: asked for now, stored when this one is done with the image
+    if (more) slab64_load(Cs, ldc, co0 + 64, co1 + 64, bt);
+    v4d acc0, acc1;
+    solve64_blocks(pan, Bs, rb, h, g, n, acc0, acc1);
+    __syncthreads();                                            // every wavefront has read what it needs of the unsolved image
+    {
+      double* U0 = Bs + 2 * h * T16_HALF;
+      double* G0 = look ? nullptr : const_cast<double*>(Cs) + (h ? co1 : co0) + 64 * pass;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + g + 4 * r;
+        U0[row * 16 + n] = acc0[r]; U0[T16_HALF + row * 16 + n] = acc1[r];
+        if (!look) { G0[(int64_t)row * ldc + n] = acc0[r]; G0[(int64_t)row * ldc + 16 + n] = acc1[r]; }   // (in place)
+      }
+    }
+    __syncthreads();                                            // the solved image is complete
+    if (look) break;
+    // the slab's share of the forward substitution / alpha update, in trsm_slab's order: wavefront (mw, cb) = 32 rows of column block cb
+    {
+      const int mw = wave >> 2, cb = wave & 3;
+      double sp = 0.0;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * mw + 16 * ti + g + 4 * r;
+          sp = __builtin_fma(Bs[cb * T16_HALF + row * 16 + n], zs[row], sp);
+        }
+      sp += __shfl_xor(sp, 16, 64);
+      sp += __shfl_xor(sp, 32, 64);
+      if (lane < 16) red[mw][cb * 16 + lane] = sp;
+    }
+    __syncthreads();
+    if (t < 64) {
+      double tot = 0.0;
+#pragma unroll
+      for (int mw = 0; mw < 4; ++mw) tot += red[mw][t];
+      const int64_t gidx = b * P.sVec + jb * NB + 64 * (half0 + pass) + t;
+      if (jb > k) P.r[gidx] -= tot; else P.alpha[gidx] += tot;
+    }
+    if (more) slab64_put(Bs, bt);                               // (the image is free: every wavefront read its share for the sums before the last barrier)
+  }
+  if (look && mine) {
+    // the block's 32 k-steps in order from -C -- the very sequence of a trailing-update tile: same bits as every other schedule
+    const double* u1 = Bs + bi * T16_HALF + g * 16 + n;
+    const double* u2 = Bs + bj * T16_HALF + g * 16 + n;
+    d = -d;
+#pragma clang loop unroll(disable)
+    for (int q4 = 0; q4 < NB / 16; ++q4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[(4 * q4 + u) * 64], u2[(4 * q4 + u) * 64], d, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cd[(int64_t)4 * r * P.ld] = -d[r];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The row solve of batches (panel / left-looking sweeps, where the launch is throughput work, not a link of a latency chain).
 // The slab kernel above runs one 128-deep product per workgroup behind a fresh copy of U_kk^-1: 160 KB fetched for 2 us of
 // MFMA, the launch bound by prologues (64 x N=2048: 97 us per block row at a quarter of the matrix pipe).  Here a workgroup

@@ -1530,6 +1530,39 @@ def test_windows_for_small_batches_are_bit_for_bit_the_plain_fused_sweep(dev, mo
         assert _rel(outs["-1"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
+@pytest.mark.parametrize("n,batch,need_grad", [(2048, 8, True), (1000, 4, True), (1100, 12, True), (640, 20, True), (2500, 5, False), (3000, 2, True)])
+def test_row_solve_of_small_batches_is_bit_for_bit_the_slab_kernels(dev, monkeypatch, n, batch, need_grad):
+    """k_trsm64 (round 5: a handful of light curves in the fused sweep -- 128 x 64 slabs, two 16 x 16 blocks per wavefront side by
+    side, 6 look-ahead workgroups per light curve, the launch's update sub-tiles as a launch of their own) against the staged
+    slab kernel k_trsm (PGM_TRSM64=0): every 16 x 16 block receives the same k-steps in the same order and the forward-
+    substitution sums are formed in the slab kernel's order, so EVERY output is the same bit for bit -- one slab per workgroup
+    (4 x N=1000, 2 x N=3000), whole blocks (8 x N=2048, 12 x N=1100, 20 x N=640), value only, a last block that ends in padding;
+    and the first light curve against the oracle."""
+    gen = torch.Generator().manual_seed(7 * n + batch)
+    X = torch.sort(torch.rand(batch, n, generator=gen, dtype=D) * 1500, dim=1)[0].to(dev)
+    Y = torch.randn(batch, n, generator=gen, dtype=D).to(dev)
+    Z = (0.01 + 0.05 * torch.rand(batch, n, generator=gen, dtype=D)).to(dev)
+    w = torch.tensor([0.6, 0.3, 0.2], dtype=D); mu = torch.tensor([[0.02], [0.11], [0.3]], dtype=D); v = torch.tensor([[0.003], [0.01], [0.02]], dtype=D)
+    outs = {}
+    for sw in ("1", "0"):                                     # (1: k_trsm64 whenever its launch fits one round; 0: never)
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_TRSM64", sw)
+        o = _hip.mll_value_grad(X.unsqueeze(-1), Y, torch.full_like(Y, 0.1), Z, None, w.to(dev).expand(batch, -1).contiguous(),
+                                mu.to(dev).expand(batch, -1, -1).contiguous(), v.to(dev).expand(batch, -1, -1).contiguous(), 0, 0.0, need_grad)
+        torch.cuda.synchronize()
+        outs[sw] = {k: t.clone().cpu() for k, t in o.items() if torch.is_tensor(t)}
+    monkeypatch.delenv("PGM_TRSM64")
+    _hip.release_workspaces()
+    assert int(outs["1"]["info"].abs().sum()) == 0 and torch.isfinite(outs["1"]["mll"]).all()
+    for key in (("mll", "g_w", "g_mu", "g_v", "g_noise", "g_mean") if need_grad else ("mll",)):
+        assert torch.equal(outs["1"][key], outs["0"][key]), key
+    val, gr = orc.mll_value_grad_closed_form(X[0].cpu(), Y[0].cpu(), 0.1, Z[0].cpu(), w, mu, v, 0, 0.0)
+    assert abs(float(outs["1"]["mll"][0]) - float(val)) < MLL_TOL
+    if need_grad:
+        for p in ("w", "mu", "v"):
+            assert _rel(outs["1"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
+
+
 @pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 3970, 5120, 5130])
 def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, n):
     """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
