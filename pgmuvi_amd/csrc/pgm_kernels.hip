@@ -1185,6 +1185,9 @@ __device__ __forceinline__ void solve_slab16(const double* __restrict__ Uinv, do
   __syncthreads();
   if (h < halves) {                                           // (uniform) 4 (rb + 1) k-steps in order, fragments one group of four ahead
     v4d acc = {0.0, 0.0, 0.0, 0.0};
+#ifdef PGM_RELAX_TRSM          // (lab build, DESIGN section 12: the k-steps of a block dealt to two accumulators -- other bits, half the dependent chain)
+    v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+#endif
     const double* pa = pan + t16_panel(rb) + g * 16 + n;
     const double* pb = Bs + h * T16_HALF + g * 16 + n;
     double a[4], bq[4];
@@ -1196,11 +1199,22 @@ __device__ __forceinline__ void solve_slab16(const double* __restrict__ Uinv, do
       const int nx = (gq < rb) ? gq + 1 : gq;                  // (the last group reads its own fragments again: no branch in the loop)
 #pragma unroll
       for (int u = 0; u < 4; ++u) { an[u] = pa[(4 * nx + u) * 64]; bn[u] = pb[(4 * nx + u) * 64]; }
+#ifdef PGM_RELAX_TRSM
+#pragma unroll
+      for (int u = 0; u < 4; u += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], bq[u + 1], acc2, 0, 0, 0);
+      }
+#else
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bq[u], acc, 0, 0, 0);
+#endif
 #pragma unroll
       for (int u = 0; u < 4; ++u) { a[u] = an[u]; bq[u] = bn[u]; }
     }
+#ifdef PGM_RELAX_TRSM
+    acc += acc2;
+#endif
     double* Us = Bs + (2 + h) * T16_HALF;
     double* Ch = Cs + (h ? hsplit : 0);
 #pragma unroll
@@ -1243,14 +1257,26 @@ __global__ __launch_bounds__(T16_THREADS) void k_trsm16(PgmDev P, int k, int nsl
       const double* u1 = Us + g * 16 + n;
       const double* u2 = Us + (halves - 1) * T16_HALF + g * 16 + n;
       d = -d;
+#ifdef PGM_RELAX_TRSM          // (lab build: the four k-steps of a row block on four accumulators, summed at the end)
+      v4d dx[3] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+#endif
 #pragma clang loop unroll(disable)
       for (int rbn = 0; rbn < NB / 16; ++rbn) {
         // (bounded: a flag that never comes -- it cannot, the wavefronts of a workgroup are resident together -- ends in a wrong
         //  block and a failed factorisation, not in a hang)
         for (int spin = 0; spin < (1 << 22) && (done[t16_wave(rbn, 0)] == 0 || done[t16_wave(rbn, halves - 1)] == 0); ++spin) __builtin_amdgcn_s_sleep(1);
+#ifdef PGM_RELAX_TRSM
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[(4 * rbn) * 64], u2[(4 * rbn) * 64], d, 0, 0, 0);
+#pragma unroll
+        for (int u = 1; u < 4; ++u) dx[u - 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[(4 * rbn + u) * 64], u2[(4 * rbn + u) * 64], dx[u - 1], 0, 0, 0);
+#else
 #pragma unroll
         for (int u = 0; u < 4; ++u) d = __builtin_amdgcn_mfma_f64_16x16x4f64(u1[(4 * rbn + u) * 64], u2[(4 * rbn + u) * 64], d, 0, 0, 0);
+#endif
       }
+#ifdef PGM_RELAX_TRSM
+      d = (d + dx[0]) + (dx[1] + dx[2]);
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cd[(int64_t)4 * r * P.ld] = -d[r];
     }
