@@ -197,6 +197,26 @@ int pgm_fit_read(pgm_fit* fit, void* stream, int* iters_done, double* loss_hist,
 int pgm_fit_destroy(pgm_fit* fit);
 
 /*
+ * The sampler's potential on the device (BASELINE config 5; the model the reference's disabled
+ * Lightcurve.mcmc describes, pgmuvi/lightcurve.py:5964-6003, with the priors of set_default_priors, :3235-3330).  For `batch`
+ * chains, each on its own light curve (x batch x n x d, y batch x n, noise batch x n or NULL = a learned noise variance; device
+ * pointers that must outlive the handle), with the per-chain unconstrained vector
+ *     z = [c, log w (q), log mu (q d), log v (q d) (, log sigma^2)],   P = 1 + q + 2 q d (+ 1),
+ * pgm_pot_eval returns   U(z) = -[ N mll(theta(z)) + sum_p log Normal(z_p; loc_p, scale_p) ]   and dU/dz  (a LogNormal(loc,
+ * scale) prior on a positive site plus the Jacobian of theta = exp z IS the Normal(loc, scale) density of z; the mean constant
+ * carries a Normal prior on its value).  loc_host / scale_host: batch x P host arrays (scale > 0).  z_host, u_host (batch),
+ * g_host (batch x P), info_host (batch, may be NULL) are host arrays: positions go in and results come back through host-mapped
+ * memory, one hipGraph replay per call (parameters from z, the fused evaluation, potential and gradient) -- no copy launches,
+ * no stream synchronisation; the call returns when the results have arrived.  A failed factorisation or a non-finite value
+ * gives U = +inf and a zero gradient (the sampler rejects the step).
+ */
+typedef struct pgm_pot pgm_pot;
+int pgm_pot_create(pgm_pot** out, pgm_ws* ws, int batch, const double* x, const double* y, const double* noise, int64_t n, int d, int q,
+                   int dim_order, const double* loc_host, const double* scale_host);
+int pgm_pot_eval(pgm_pot* pot, const double* z_host, double* u_host, double* g_host, int* info_host, void* stream);
+int pgm_pot_destroy(pgm_pot* pot);
+
+/*
  * Dense back-end (the reference's non-spectral-mixture models, pgmuvi/gps.py:915-1342:
  * quasi-periodic, Matern, RBF, RQ, separable products, sums): the caller supplies a = K + noise as a dense symmetric
  * matrix ([batch][n][lda], device) and r = y - mean ([batch][n]); mll[batch] is the per-datum log marginal likelihood

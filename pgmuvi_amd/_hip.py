@@ -59,6 +59,9 @@ SYMBOLS = {
     "pgm_fit_run": (c_int, [c_void_p, c_int, c_void_p]),
     "pgm_fit_read": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "pgm_fit_destroy": (c_int, [c_void_p]),
+    "pgm_pot_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pgm_pot_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pgm_pot_destroy": (c_int, [c_void_p]),
     "pgm_lomb_scargle_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p]),
     "pgm_mll_kernel_value_grad_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p,
@@ -717,6 +720,57 @@ class NativeFit:
     def close(self):
         if getattr(self, "handle", None):
             load().pgm_fit_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativePotential:
+    """Handle of the sampler's potential on the device (``pgm_pot_*``): for B chains, z (B,P) on the host -> (U (B,), dU/dz (B,P),
+    info (B,)) on the host, one hipGraph replay per call, positions and results through host-mapped memory.  ``x`` (B,n,d),
+    ``y`` (B,n), ``noise`` (B,n)|None are kept alive here; ``loc`` / ``scale`` (B,P): the Normal density of every entry of z."""
+
+    def __init__(self, x, y, noise, q, dim_order, loc, scale, workspace: Optional[Workspace] = None):
+        import numpy as np
+        require_gpu(y, "NativePotential")
+        dev = y.device
+        B, n = y.shape
+        self.x = _dev64(x.reshape(B, n, -1), dev)
+        self.y = _dev64(y, dev)
+        self.noise = None if noise is None else _dev64(noise.expand(B, n), dev)
+        d = self.x.shape[-1]
+        self.B, self.P = B, 1 + q + 2 * q * d + (1 if noise is None else 0)
+        self.ws = workspace or get_workspace(dev, n, q, d, B)
+        self.dev = dev
+        lo = np.ascontiguousarray(np.broadcast_to(np.asarray(loc, dtype=np.float64), (B, self.P)))
+        sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), (B, self.P)))
+        h = c_void_p()
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            rc = load().pgm_pot_create(byref(h), self.ws.handle, B, _ptr(self.x), _ptr(self.y), _ptr(self.noise), n, d, q, int(dim_order),
+                                       lo.ctypes.data_as(c_void_p), sc.ctypes.data_as(c_void_p))
+        _check(rc, "pgm_pot_create")
+        self.handle = h
+        self._u = np.zeros(B); self._g = np.zeros((B, self.P)); self._info = np.zeros(B, dtype=np.int32)
+
+    def __call__(self, z):
+        import numpy as np
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if z.shape != (self.B, self.P):
+            raise ValueError(f"NativePotential: z must be ({self.B}, {self.P}), got {z.shape}")
+        with torch.cuda.device(self.dev):
+            rc = load().pgm_pot_eval(self.handle, z.ctypes.data_as(c_void_p), self._u.ctypes.data_as(c_void_p),
+                                     self._g.ctypes.data_as(c_void_p), self._info.ctypes.data_as(c_void_p), current_stream_ptr(self.dev))
+        _check(rc, "pgm_pot_eval")
+        return self._u.copy(), self._g.copy(), self._info.copy()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().pgm_pot_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

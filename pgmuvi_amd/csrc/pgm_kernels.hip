@@ -2631,6 +2631,97 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
   if (t == 0) F.it[0] = it + 1;
 }
 
+// ---------------------------------------------------------------------------
+// The NUTS / HMC potential of config 5 on the device (pgm_pot_*, round 5): per chain b the unconstrained vector
+//   z = [c, log w (q), log mu (q d), log v (q d) (, log sigma^2)]
+// -> theta (k_pot_pre: exp for every site but the mean constant; the mean vector, the mixture arrays and the noise variance the
+// evaluation reads), the fused evaluation, and (k_pot_post)
+//   U(z) = -[ N mll(theta) + sum_p log Normal(z_p; loc_p, scale_p) ],   dU/dz_p = -[ N dmll/dtheta_p * dtheta_p/dz_p - (z_p - loc_p) / scale_p^2 ]
+// (for a log site, LogNormal(loc, scale) on theta plus the Jacobian z is exactly the Normal(loc, scale) density of z: the
+// reference's default priors, /root/reference/pgmuvi/lightcurve.py:3235-3330, in the coordinates pyro samples).  z comes from
+// and U, dU/dz go to host-mapped memory: one graph replay per leapfrog step, no copy launches, no stream synchronisation
+// (the host polls the stamp k_pot_post leaves behind its results).
+// ---------------------------------------------------------------------------
+struct PotDev {
+  int B, P, n, q, qd, has_noise;
+  const double* z;        // [B][P] host-mapped: this tick's positions
+  const double* loc;      // [B][P]
+  const double* scale;    // [B][P]
+  double* theta;          // [B][P]
+  double* mean_vec;       // [B][n]
+  double* w;              // [B][q]
+  double* mu;             // [B][qd]
+  double* v;              // [B][qd]
+  double* noise_scalar;   // [B]
+  double* res;            // [B][1 + P] host-mapped: U, dU/dz
+  int* res_info;          // [B] host-mapped
+  long long* res_seq;     // [B] host-mapped: the tick number behind res (written last, system scope)
+  const long long* tick;  // [1] host-mapped: this tick's number
+};
+
+__global__ __launch_bounds__(256) void k_pot_pre(PotDev F) {
+  const int b = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+  const double* z = F.z + (int64_t)b * F.P;
+  if (blockIdx.x == 0 && threadIdx.x < F.P) {
+    const int p = threadIdx.x;
+    const double th = p == 0 ? z[0] : exp(z[p]);
+    F.theta[(int64_t)b * F.P + p] = th;
+    if (p >= 1 && p < 1 + F.q) F.w[(int64_t)b * F.q + p - 1] = th;
+    else if (p >= 1 + F.q && p < 1 + F.q + F.qd) F.mu[(int64_t)b * F.qd + p - 1 - F.q] = th;
+    else if (p >= 1 + F.q + F.qd && p < 1 + F.q + 2 * F.qd) F.v[(int64_t)b * F.qd + p - 1 - F.q - F.qd] = th;
+    else if (p >= 1) F.noise_scalar[b] = th;
+  }
+  if (i < F.n) F.mean_vec[(int64_t)b * F.n + i] = z[0];
+}
+
+// one workgroup per chain
+__global__ __launch_bounds__(256) void k_pot_post(PotDev F, const double* __restrict__ mll, const double* __restrict__ g_w,
+                                                  const double* __restrict__ g_mu, const double* __restrict__ g_v,
+                                                  const double* __restrict__ g_noise, const double* __restrict__ g_mean,
+                                                  const int* __restrict__ info) {
+  __shared__ double red[256], sums[2], lpsum;
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int which = 0; which < 2; ++which) {                   // sum of dmll/dmean_i; of dmll/dnoise_i (a learned noise variance)
+    double s = 0.0;
+    if (which == 0) for (int i = t; i < F.n; i += 256) s += g_mean[(int64_t)b * F.n + i];
+    else if (F.has_noise) for (int i = t; i < F.n; i += 256) s += g_noise[(int64_t)b * F.n + i];
+    red[t] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
+    if (t == 0) sums[which] = red[0];
+    __syncthreads();
+  }
+  constexpr double HALF_LOG_2PI = 0.91893853320467274178;
+  double lp = 0.0, g = 0.0;
+  const int64_t o = (int64_t)b * F.P;
+  if (t < F.P) {
+    const int p = t;
+    const double zz = (F.z[o + p] - F.loc[o + p]) / F.scale[o + p];
+    lp = -0.5 * zz * zz - log(F.scale[o + p]) - HALF_LOG_2PI;
+    double gth;                                               // dmll / dtheta_p
+    if (p == 0) gth = sums[0];
+    else if (p < 1 + F.q) gth = g_w[(int64_t)b * F.q + p - 1];
+    else if (p < 1 + F.q + F.qd) gth = g_mu[(int64_t)b * F.qd + p - 1 - F.q];
+    else if (p < 1 + F.q + 2 * F.qd) gth = g_v[(int64_t)b * F.qd + p - 1 - F.q - F.qd];
+    else gth = sums[1];
+    const double gl = p == 0 ? gth : gth * F.theta[o + p];      // d/dz = theta d/dtheta for the log sites
+    g = -((double)F.n * gl - zz / F.scale[o + p]);
+  }
+  red[t] = lp;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
+  if (t == 0) lpsum = red[0];
+  __syncthreads();
+  const double U = -((double)F.n * mll[b] + lpsum);
+  const bool bad = info[b] != 0 || !isfinite(U);
+  double* res = F.res + (int64_t)b * (1 + F.P);
+  if (t == 0) { res[0] = bad ? __builtin_huge_val() : U; F.res_info[b] = info[b]; }
+  if (t < F.P) res[1 + t] = bad ? 0.0 : g;
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) F.res_seq[b] = F.tick[0];
+}
+
 #include "pgm_generic.inc"
 
 }  // namespace

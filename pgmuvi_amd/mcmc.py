@@ -82,6 +82,10 @@ class SMPotential:
         self.dim_order = dim_order
         self.device = y.device
         self._compute = compute or _hip.mll_value_grad
+        # (on the GPU, without a stand-in evaluation: transforms, priors, Jacobians and the chain rule run on the device too --
+        #  ``pgm_pot_*``, one graph replay per tick; made on the first call)
+        self._native = None
+        self._use_native = compute is None and self.device.type == "cuda"
         Q, d, B = self.Q, self.d, self.B
         ymean = self.y.mean(-1).cpu().numpy().reshape(B, 1)
         ystd = self.y.std(-1).cpu().numpy().reshape(B, 1)
@@ -149,6 +153,12 @@ class SMPotential:
         and one download -- a tick is latency-bound, and every small device op it does not issue is ~10 us saved."""
         B, Q, d, N = self.B, self.Q, self.d, self.N
         z = np.ascontiguousarray(z, dtype=np.float64)
+        if self._use_native:
+            if self._native is None:
+                self._native = _hip.NativePotential(self.x, self.y, self.noise, Q, self.dim_order, self._loc_h, self._scale_h)
+            U, g, _info = self._native(z)
+            self.evaluations += B
+            return U, g
         theta = z.copy()
         theta[:, 1:] = np.exp(z[:, 1:])                                 # every site but the mean is sampled as a logarithm
         tt = torch.from_numpy(theta).to(self.device)

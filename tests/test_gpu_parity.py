@@ -843,6 +843,41 @@ def test_nuts_potential_and_short_run_vs_oracle(dev):
         assert np.allclose(a[k], b[k], rtol=1e-6, atol=1e-9), k
 
 
+def test_native_potential_equals_the_python_one(dev):
+    """``pgm_pot_*`` (round 5: z -> theta, priors, Jacobians and the chain rule on the device, positions and results through
+    host-mapped memory, one graph replay per tick) against the same potential assembled on the host from the plain batched
+    evaluation: equal to round-off for fixed and learned noise, 1-D and 2-D, tick after tick on one handle; a position whose
+    matrix cannot be factored gives U = +inf and a zero gradient in both."""
+    from pgmuvi_amd import mcmc
+    rng = np.random.default_rng(21)
+    for (C, n, Q, d, learn) in ((3, 300, 2, 1, False), (2, 700, 3, 1, True), (2, 260, 2, 2, False), (1, 2048, 4, 1, False)):
+        x = torch.sort(torch.rand(C, n, generator=torch.Generator().manual_seed(n), dtype=D) * 900, dim=1)[0]
+        xx = x.unsqueeze(-1) if d == 1 else torch.stack([x, torch.rand(C, n, generator=torch.Generator().manual_seed(n + 1), dtype=D) * 2], dim=-1)
+        y = torch.randn(C, n, generator=torch.Generator().manual_seed(n + 2), dtype=D)
+        nz = 0.02 + 0.05 * torch.rand(C, n, generator=torch.Generator().manual_seed(n + 3), dtype=D)
+        native = mcmc.SMPotential(xx.to(dev), y.to(dev), None if learn else nz.to(dev), num_mixtures=Q)
+        host = mcmc.SMPotential(xx.to(dev), y.to(dev), None if learn else nz.to(dev), num_mixtures=Q)
+        host._use_native = False
+        assert native._use_native
+        for tick in range(3):
+            z = rng.normal(0, 0.3, (C, native.P))
+            z[:, 1 + Q:1 + Q + Q * d] += np.log(1 / 120.0)
+            z[:, 1 + Q + Q * d:1 + Q + 2 * Q * d] += np.log(1 / 1200.0)
+            if learn:
+                z[:, -1] = np.log(0.02)
+            Un, Gn = native(z)
+            Uh, Gh = host(z)
+            assert np.isfinite(Un).all() and np.allclose(Un, Uh, rtol=1e-12, atol=1e-9), (C, n, tick, Un, Uh)
+            assert np.allclose(Gn, Gh, rtol=1e-9, atol=1e-9 * n)
+        if not learn:
+            z[0, 1 + Q + Q * d:1 + Q + 2 * Q * d] = np.log(1e-9)          # (all but constant mixtures, tiny noise relative to them: not positive definite in fp64)
+            z[0, 1:1 + Q] = np.log(1e8)
+            Un, Gn = native(z)
+            Uh, Gh = host(z)
+            assert np.isinf(Un[0]) == np.isinf(Uh[0]) and np.array_equal(Gn[0] == 0.0, Gh[0] == 0.0)
+            assert np.allclose(Un[1:], Uh[1:], rtol=1e-12, atol=1e-9)
+
+
 def test_config5_at_its_stated_size(dev):
     """BASELINE config 5 as stated -- 8 chains x (N=2048, Q=4), default priors (``pgmuvi/lightcurve.py:3235-3330``) -- in one
     batched HIP evaluation per tick: potential and gradient of the first and the last chain against the oracle's autograd, then
