@@ -284,11 +284,11 @@ def sweep_roofline(prof, ws, n, nloc, steps):
     return roofline
 
 
-EXP_PAIR_INSTRS = 27      # fp64 VALU instructions per (pair, mixture) of the 1-D build in round 3 (20 of them the branch-free exp):
-                          # `exp_issue_floor_us` keeps this count and 4 cycles per instruction, the figure VERDICT r03 prices against
-BUILD_PAIR_INSTRS = 24    # the count since round 4 (18 for the exp: no clamp; the 2 pi^2 folded into the staged factors; the weight on the column factors)
-VALU_F64_CYCLES = 5.5     # measured issue cost of an fp64 VALU instruction per wavefront and SIMD (tools/lab/ratelab: 5.3-5.9 for every
-                          # instruction of the exp, v_fma_f64 included -- not the 4 of 16 lanes per clock)
+BUILD_PAIR_INSTRS = 24    # fp64 VALU instructions per (pair, mixture) of the 1-D build (18 of them the branch-free exp)
+VALU_F64_CYCLES = 5.5     # MEASURED issue cost of an fp64 VALU instruction per wavefront and SIMD on this part: tools/lab/ratelab issues
+                          # long dependent-free runs of each instruction of the exp (v_fma_f64, v_mul_f64, v_add_f64, v_max_f64, v_rndne_f64,
+                          # v_cvt_i32_f64, v_ldexp_f64) at 1, 2 and 4 wavefronts per SIMD and divides clock ticks by instructions: 5.3-5.9
+                          # cycles for every one of them (profiles/r04_ratelab.txt) -- not the 4 of "16 lanes per clock"
 
 
 def build_roofline(prof, n, nloc, q=4, beside=False):
@@ -302,8 +302,7 @@ def build_roofline(prof, n, nloc, q=4, beside=False):
     build_bytes = 8.0 * NB * NB * ntiles * nloc
     us = build_ms / max(build_launches, 1) * 1e3
     gbs = build_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
-    # 256 CUs x 4 SIMDs x 16 fp64 lanes per clock at 2.4 GHz
-    exp_floor_us = ntiles * nloc * NB * NB * q * EXP_PAIR_INSTRS / (256 * 4 * 16 * 2.4e3)
+    # the floor of the build's arithmetic: its fp64 VALU instructions at the measured issue rate, 256 CUs x 4 SIMDs at 2.4 GHz
     valu_floor_us = ntiles * nloc * NB * NB * q * BUILD_PAIR_INSTRS * VALU_F64_CYCLES / (256 * 4 * 64 * 2.4e3)
     kernel = "k_build (spectral-mixture kernel matrix, upper block triangle, one launch)"
     if beside:
@@ -312,10 +311,11 @@ def build_roofline(prof, n, nloc, q=4, beside=False):
                    "the first k_diag launch, hidden beside diagonal block 0 (up to 55 tiles: factors and matrix by one launch, k_prebuild)")
     return dict(bound="hbm", kernel=kernel, achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
                 avg_launch_us=round(us, 2), bytes_per_launch=build_bytes,
-                exp_issue_floor_us=round(exp_floor_us, 2), frac_of_exp_issue_floor=round(exp_floor_us / us, 4) if us > 0 else None,
                 instructions_per_pair_and_mixture=BUILD_PAIR_INSTRS, valu_cycles_per_instruction_measured=VALU_F64_CYCLES,
                 valu_floor_us_at_measured_issue_rate=round(valu_floor_us, 2),
-                frac_of_valu_floor_at_measured_issue_rate=round(valu_floor_us / us, 4) if us > 0 else None)
+                frac_of_valu_floor_at_measured_issue_rate=round(valu_floor_us / us, 4) if us > 0 else None,
+                note="the build is bound by the Q N^2 / 2 fp64 exp it evaluates (VALU issue), not by HBM: the floor beside the GB/s is that arithmetic "
+                     "at the measured issue rate of the instructions (tools/lab/ratelab)")
 
 
 def whole_build_profile(dev, data, n, reps=5):

@@ -1901,7 +1901,7 @@ def test_bench_collective_path_on_rccl(dev):
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         out = json.loads(line)
         assert out["scaling"] == scaling and out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
-        assert out["roofline_build"]["frac"] > 0 and out["roofline_build"]["exp_issue_floor_us"] > 0
+        assert out["roofline_build"]["frac"] > 0 and out["roofline_build"]["valu_floor_us_at_measured_issue_rate"] > 0
 
 
 def test_ragged_step_gathers_over_rccl(dev):
