@@ -132,7 +132,8 @@ struct pgm_ws {
   int trsm64;            // fused sweep, a handful of light curves: the row solve by k_trsm64 (128 x 64 slabs, 6 look-ahead workgroups per light curve)
   int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on
   int pairs;             // fused sweep: two-source filler passes allowed (run_sweep)
-  int build_beside;      // one light curve, 1-D spectral mixture: build the matrix below block row 0 beside diagonal block 0 (PGM_BUILD_BESIDE=0: off)
+  int build_beside;      // 1-D spectral mixture, fused sweep: most light curves per call whose matrix below block row 0 is built beside
+                         //   diagonal block 0 (PGM_BUILD_BESIDE; 0: never, 1: one light curve only, default 8)
   int lazy, lazy_end;    // fused sweep: lazy plan (run_sweep), and the tile count from which it turns eager
   int lookahead;         // fused sweep: first block row whose successor's diagonal tile is formed inside the row-solve launch
                          //   (no head launch on the chain from there on); >= 64: never
