@@ -1825,6 +1825,10 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
   const double* Rt = cont ? P.R + ((int64_t)i * NB + mo) * ld + j * NB + no : nullptr;
   auto operands = [&](int kb, const double*& pa, int64_t& lda, const double*& pb, int64_t& ldb) {
     const int p = p0 + kb;
+#ifdef PGM_LAUUM_HOT            // (lab build, timing only: every work item multiplies the same two tiles -- what would perfect L2 locality be worth?)
+    pa = A + (int64_t)(P.nb - 1) * NB * ld + mo; lda = ld; pb = A + (int64_t)(P.nb - 1) * NB * ld + NB + no; ldb = ld;
+    return;
+#endif
     if (p > i) { pa = A + (int64_t)p * NB * ld + i * NB + mo; lda = ld; }
     else { pa = Dv + ((int64_t)i * 2 + 1) * NB * NB + mo; lda = NB; }
     if (p > j) { pb = A + (int64_t)p * NB * ld + j * NB + no; ldb = ld; }
