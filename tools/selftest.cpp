@@ -250,6 +250,53 @@ int main(int argc, char** argv) {
       fails += !(ev == 0.0) + !(eg < 1e-9);
     }
   }
+  // the sampler's potential on the device (pgm_pot_*): U and dU/dz for two chains against the same formula assembled here from the
+  // batched evaluation at theta = (c, exp z): U = -(N mll + sum log Normal(z; loc, scale)), dU/dz by the chain rule
+  {
+    const int B = 2, n = 300, q = 3, P = 1 + 3 * q;
+    vector<Problem> ps; for (int b = 0; b < B; ++b) ps.push_back(make_problem(n, 1, q, 0, 300 + b));
+    vector<double> X, Y, NZ, Z((size_t)B * P), LOC((size_t)B * P), SC((size_t)B * P), W, MU, V, M;
+    for (int b = 0; b < B; ++b) {
+      auto& p = ps[b];
+      X.insert(X.end(), p.x.begin(), p.x.end()); Y.insert(Y.end(), p.y.begin(), p.y.end()); NZ.insert(NZ.end(), p.noise.begin(), p.noise.end());
+      double* z = &Z[(size_t)b * P];
+      z[0] = 0.07 - 0.1 * b;
+      for (int a = 0; a < q; ++a) { z[1 + a] = std::log(p.w[a]); z[1 + q + a] = std::log(p.mu[a]); z[1 + 2 * q + a] = std::log(p.v[a]); }
+      for (int e = 0; e < P; ++e) { LOC[(size_t)b * P + e] = e == 0 ? 0.1 : -1.0 - 0.3 * e; SC[(size_t)b * P + e] = e == 0 ? 0.5 : 1.5 + 0.1 * e; }
+      W.insert(W.end(), p.w.begin(), p.w.end()); MU.insert(MU.end(), p.mu.begin(), p.mu.end()); V.insert(V.end(), p.v.begin(), p.v.end());
+      for (int i = 0; i < n; ++i) M.push_back(z[0]);
+    }
+    double *x = dev(X), *y = dev(Y), *nz = dev(NZ), *w = dev(W), *mu = dev(MU), *v = dev(V), *m = dev(M);
+    vector<double> zb(B), zq(B * q), zn((size_t)B * n); vector<int> zi(B);
+    double *mll = dev(zb), *gw = dev(zq), *gmu = dev(zq), *gv = dev(zq), *gn = dev(zn), *gm = dev(zn); int* info = dev(zi);
+    rc = pgm_mll_value_grad_batched_f64(ws, B, x, y, m, nz, nullptr, n, 1, w, mu, v, q, 0, 0.0, 1, mll, gw, gmu, gv, gn, gm, info, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto hm = host(mll, B); auto hgw = host(gw, B * q); auto hgmu = host(gmu, B * q); auto hgv = host(gv, B * q); auto hgm = host(gm, (size_t)B * n);
+    pgm_pot* pot = nullptr;
+    int rcp = pgm_pot_create(&pot, ws, B, x, y, nz, n, 1, q, 0, LOC.data(), SC.data());
+    vector<double> U(B), G((size_t)B * P); vector<int> inf(B);
+    for (int rep = 0; rep < 2 && rcp == 0; ++rep) rcp = pgm_pot_eval(pot, Z.data(), U.data(), G.data(), inf.data(), nullptr);
+    for (int b = 0; b < B; ++b) {
+      const double* z = &Z[(size_t)b * P];
+      double lp = 0, gsum = 0;
+      for (int i = 0; i < n; ++i) gsum += hgm[(size_t)b * n + i];
+      vector<double> gref(P);
+      for (int e = 0; e < P; ++e) {
+        const double t = (z[e] - LOC[(size_t)b * P + e]) / SC[(size_t)b * P + e];
+        lp += -0.5 * t * t - std::log(SC[(size_t)b * P + e]) - 0.91893853320467274178;
+        double gth = e == 0 ? gsum : (e < 1 + q ? hgw[b * q + e - 1] : e < 1 + 2 * q ? hgmu[b * q + e - 1 - q] : hgv[b * q + e - 1 - 2 * q]);
+        if (e > 0) gth *= std::exp(z[e]);
+        gref[e] = -(n * gth - t / SC[(size_t)b * P + e]);
+      }
+      const double Uref = -(n * hm[b] + lp);
+      double eg = 0;
+      for (int e = 0; e < P; ++e) eg = std::fmax(eg, std::fabs(G[(size_t)b * P + e] - gref[e]) / (std::fabs(gref[e]) + 1e-9));
+      const double eu = std::fabs(U[b] - Uref) / (std::fabs(Uref) + 1.0);
+      printf("potential[%d]: rc=%d U=%.9f |dU| rel %.1e %s, dU/dz rel %.1e %s, info %d\n", b, rcp, U[b], eu, eu < 1e-12 ? "OK" : "FAIL", eg, eg < 1e-9 ? "OK" : "FAIL", inf[b]);
+      fails += !(rcp == 0 && eu < 1e-12) + !(eg < 1e-9);
+    }
+    if (pot) pgm_pot_destroy(pot);
+  }
   // non-PD detection
   {
     Problem p = make_problem(200, 1, 2, 0, 9);
