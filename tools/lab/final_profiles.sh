@@ -1,29 +1,27 @@
 # the round's evidence on the final library: kernel stats, PMC traffic, MfmaUtil, timeline per workload (tools/profile.sh), and
-# the kernel statistics of bench.py itself
+# the kernel statistics of bench.py itself.  tools/lab/final_profiles.sh [a|b]: the first / second half (one GPU call each)
 set -e
 cd $GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+part=${1:-ab}
+if [[ $part == *a* ]]; then
 bash tools/profile.sh single_n4096 4096 5 1
-bash tools/profile.sh batch512_n2048 2048 2 1 4 512
 bash tools/profile.sh cfg4_n8192_d2 8192 3 1 3 1 2
 bash tools/profile.sh cfg5_tick_8x2048 2048 5 1 4 8
+bash tools/profile.sh batch64_n2048 2048 3 1 4 64
+mkdir -p gpurun_out/prof_bench
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o stats -- python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu > gpurun_out/prof_bench/bench_line.json 2> gpurun_out/prof_bench/bench.err
+s=$(find gpurun_out/prof_bench -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_bench/kernel_stats.csv
+find gpurun_out/prof_bench -name '*_kernel_trace.csv' -delete
+fi
+if [[ $part == *b* ]]; then
+bash tools/profile.sh batch512_n2048 2048 2 1 4 512
 bash tools/profile.sh batch256_n4096 4096 1 1 4 256
 # the ragged batch of tools/raggedbench.py (512 light curves, N ~ U{1024..2048}: one trimmed launch set): kernel statistics and timeline
 mkdir -p gpurun_out/prof_ragged512
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ragged512 -o stats -- python3 tools/lab/ragprof.py 512 1024 2048 3 > gpurun_out/prof_ragged512/stats.log 2>&1
 s=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_ragged512/kernel_stats.csv
 k=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_trace.csv' | head -1); python3 tools/timeline.py "$k" > gpurun_out/prof_ragged512/timeline.txt
-d=gpurun_out/prof_ragged512; export PGM_PROFILE_WORKLOAD="python3 tools/lab/ragprof.py 512 1024 2048 3"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d -o fetch -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d -o write -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $d -o tcc -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/tcc.log 2>&1
-rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $d -o mfma -- python3 tools/lab/ragprof.py 512 1024 2048 3 > $d/mfma.log 2>&1
-python3 tools/pmc_counter.py "$(find $d -name 'mfma_counter_collection.csv' | head -1)" MfmaUtil > $d/mfma_util.json
-python3 tools/pmc_traffic.py "$(find $d -name 'fetch_counter_collection.csv' | head -1)" "$(find $d -name 'write_counter_collection.csv' | head -1)" $(find $d -name 'tcc_counter_collection.csv' | head -1) > $d/traffic.json
-find $d -name '*_counter_collection.csv' -delete
 find gpurun_out/prof_ragged512 -name '*_kernel_trace.csv' -delete
-mkdir -p gpurun_out/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o stats -- python3 bench.py --steps 20 --warmup 3 --no-extra --no-cpu > gpurun_out/prof_bench/bench_line.json 2> gpurun_out/prof_bench/bench.err
-s=$(find gpurun_out/prof_bench -name 'stats_kernel_stats.csv' | head -1); cp "$s" gpurun_out/prof_bench/kernel_stats.csv
-find gpurun_out/prof_bench -name '*_kernel_trace.csv' -delete
+fi
 sha256sum pgmuvi_amd/libpgmuvi_hip.so > gpurun_out/prof_lib_sha.txt

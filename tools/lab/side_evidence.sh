@@ -15,7 +15,8 @@ python3 tools/densebench.py > $o/densebench.txt 2>&1
 python3 tools/raggedbench.py 512 1024 2048 3 > $o/raggedbench.txt 2>&1
 python3 tools/raggedbench.py 512 200 2300 3 >> $o/raggedbench.txt 2>&1
 for a in "64 1024 2048" "128 300 1500" "32 500 3000" "16 1024 2048" "12 1024 2048" "8 1024 2048"; do python3 tools/raggedbench.py $a 3; done >> $o/raggedbench.txt 2>&1
-( CHAINS=1 SAMPLES=10 WARMUP=20 python3 tools/nutsbench.py | awk "NR<=2"; CHAINS=8 SAMPLES=10 WARMUP=20 python3 tools/nutsbench.py | awk "NR<=2" ) > $o/nutsbench_ticks.txt 2>&1
+( CHAINS=1 SAMPLES=10 WARMUP=20 python3 tools/nutsbench.py 2>/dev/null | awk "NR<=2"; CHAINS=8 SAMPLES=10 WARMUP=20 python3 tools/nutsbench.py 2>/dev/null | awk "NR<=2" ) > $o/nutsbench_ticks.txt 2>&1
+tools/selftest 1024 > $o/selftest.txt 2>&1
 [ -x tools/lab/ratelab ] && tools/lab/ratelab > $o/ratelab.txt 2>&1
 [ -x tools/lab/potrflab ] && tools/lab/potrflab 2000 > $o/potrflab.txt 2>&1
 sha256sum pgmuvi_amd/libpgmuvi_hip.so > $o/lib_sha.txt
