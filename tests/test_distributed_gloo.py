@@ -3,6 +3,7 @@ evaluate their shards (oracle stand-in for the HIP call: no GPU here) and all_ga
 log-likelihoods; the result must equal the single-process evaluation of the whole batch."""
 import os
 import socket
+import subprocess
 import sys
 
 import pytest
@@ -262,3 +263,37 @@ def test_bench_refuses_more_ranks_than_devices_before_touching_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--no-cpu"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
+
+
+def test_launcher_passes_a_signal_on_and_reports_it():
+    """A driver that ends ``python bench.py --gpus N`` on a time-out sends the PARENT a SIGTERM: the launcher passes it on to its
+    ranks, gives them ``grace_s`` to leave (they hold GPUs and an RCCL group), and returns 128 + the signal as a shell would
+    (ADVICE r04); nothing of the job is left behind."""
+    import signal
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os\nsys.path.insert(0, %r)\nfrom pgmuvi_amd import launch\nprint('ready', flush=True)\n"
+            "rc = launch.spawn_ranks([sys.executable, '-c', 'import time; time.sleep(120)'], 2, grace_s=5.0, out=sys.stderr)\n"
+            "print('rc', rc, flush=True)\nsys.exit(rc)\n" % root)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True)
+    try:
+        assert p.stdout.readline().strip() == "ready"
+        time.sleep(1.0)
+        kids = [d for d in os.listdir("/proc") if d.isdigit() and _parent_of(d) == str(p.pid)]
+        assert len(kids) == 2
+        t0 = time.time()
+        p.send_signal(signal.SIGTERM)
+        out, _ = p.communicate(timeout=30)
+        assert p.returncode == 128 + signal.SIGTERM and "rc 143" in out and time.time() - t0 < 10
+        time.sleep(0.3)
+        assert not [k for k in kids if os.path.exists(f"/proc/{k}")]
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+def _parent_of(pid):
+    try:
+        return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[1]
+    except OSError:
+        return ""
