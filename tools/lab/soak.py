@@ -57,3 +57,37 @@ for rep in range(20): o = run(0)
 torch.cuda.synchronize(); same2 = (time.time() - t0) / 20 * 1e3
 print(f"ragged: 60 alternating calls of three batches on one workspace, {bad} mismatches; {alt:.2f} ms per call alternating (every call uploads its "
       f"table and re-captures its launch graphs) against {same:.2f} / {same2:.2f} ms for the first batch repeated")
+
+# round 5: the sampler's potential (pgm_pot_*: a captured tick with workspace addresses and the early-pass tables baked in) interleaved
+# with plain evaluations and small batches on the SAME cached workspaces -- every result must repeat bit for bit
+import numpy as np
+from pgmuvi_amd import mcmc
+def chains(C, n):
+    xs, ys, ns = [], [], []
+    for c in range(C):
+        (t, y, e), _ = syn.cfg3_lightcurve(5000 + c, n_obs=n)
+        xs.append(t.double().reshape(n, 1)); ys.append(y.double()); ns.append(e.double() ** 2)
+    return torch.stack(xs).to(dev), torch.stack(ys).to(dev), torch.stack(ns).to(dev)
+x1, y1, n1 = chains(1, 2048); x8, y8, n8 = chains(8, 2048); xb, yb, nb_ = chains(12, 1024)
+pot1 = mcmc.SMPotential(x1, y1, n1, num_mixtures=4); pot8 = mcmc.SMPotential(x8, y8, n8, num_mixtures=4)
+rng = np.random.default_rng(5)
+def zfor(pot):
+    z = rng.normal(0, 0.2, (pot.B, pot.P)); z[:, 5:9] += np.log(1.0 / np.array([150.0, 67.0, 400.0, 31.0])); z[:, 9:13] += np.log(0.1 / np.array([150.0, 67.0, 400.0, 31.0])); return z
+z1, z8 = zfor(pot1), zfor(pot8)
+h = syn.cfg_hypers(2, yb[0].cpu())
+wb, mub, vb = (t.to(dev).expand(12, *t.shape).contiguous() for t in (h["w"], h["mu"].reshape(4, 1), h["v"].reshape(4, 1)))
+def plain(): 
+    o = _hip.mll_value_grad(x1[0], y1[0], torch.zeros(2048, dtype=D, device=dev), n1[0], None, h["w"].to(dev), h["mu"].reshape(4, 1).to(dev), h["v"].reshape(4, 1).to(dev), 0, 0.0, True)
+    return (float(o["mll"]), float(o["g_mu"].sum()))
+def small():
+    o = _hip.mll_value_grad(xb, yb, torch.zeros(12, 1024, dtype=D, device=dev), nb_, None, wb, mub, vb, 0, 0.0, True)
+    return (float(o["mll"].sum()), float(o["g_mu"].sum()))
+first, bad = {}, 0
+t0 = time.time()
+for rep in range(40):
+    for name, f in (("pot1", lambda: tuple(np.concatenate([a.ravel() for a in pot1(z1)]))), ("plain", plain), ("pot8", lambda: tuple(np.concatenate([a.ravel() for a in pot8(z8)]))), ("small", small)):
+        r = f()
+        if name not in first: first[name] = r
+        elif first[name] != r: bad += 1; print("POTENTIAL MISMATCH", rep, name)
+torch.cuda.synchronize()
+print(f"potential soak: 160 calls (one-chain tick, plain N=2048 evaluation, eight-chain tick, 12 x N=1024 batch, alternating on shared workspaces) in {time.time() - t0:.1f} s, {bad} mismatches")
