@@ -366,7 +366,8 @@ class Harness:
         for _ in range(steps):
             res = step()
         self.fence()
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.dev)
+        on_host = dist.is_initialized() and dist.get_backend() == "gloo"
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if on_host else self.dev)
         if dist.is_initialized():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), res
@@ -394,6 +395,7 @@ def strong_scaling_run(h, total, n, steps, warmup, rank, world, dev, chunk=None,
                ms_per_step=round(elapsed / steps * 1e3, 4), light_curves_per_gpu=counts, chunk=chunk,
                algorithmic_tflops_per_gpu=round(tfl, 3), algorithmic_frac_of_fp64_mfma_peak=round(tfl / FP64_MATRIX_PEAK_TFLOPS, 4),
                loglik_checksum=float(ll.sum()))
+    res.update(fixture_deviation(ll, total, n))
     prof = None
     if profile and nloc:
         ws.profile(True)
@@ -401,6 +403,20 @@ def strong_scaling_run(h, total, n, steps, warmup, rank, world, dev, chunk=None,
         prof = ws.profile_read()
         ws.profile(False)
     return res, prof, ws, nloc, (float(ll[0]) if total else None)
+
+
+def fixture_deviation(ll, total, n):
+    """BASELINE configs[2] at its stated size: the gathered log-likelihoods of the 512 x N=2048 batch against the committed oracle
+    values (tests/golden/expect_cfg3_b512_n2048.npz, made in the build container by tests/golden/make_golden.py --fullsize from
+    inputs generated with the reference's helpers).  Numbers only are read: nothing under oracle/ is imported or run."""
+    path = os.path.join(ROOT, "tests", "golden", f"expect_cfg3_b{total}_n{n}.npz")
+    if not os.path.exists(path):
+        return {}
+    import numpy as np
+    want = torch.as_tensor(np.load(path, allow_pickle=False)["mll"], dtype=torch.float64)
+    dev_ = float((ll.detach().cpu().double() - want).abs().max())
+    return {"max_abs_dev_vs_fixture": dev_, "fixture": f"tests/golden/{os.path.basename(path)} (oracle values of all {total} light curves)",
+            "fixture_tolerance": 1e-9}
 
 
 def ragged_run(h, total, n_lo, n_hi, steps, warmup, rank, world, dev):
@@ -438,18 +454,27 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the batched / strong-scaling side measurements")
     ap.add_argument("--no-big-batch", action="store_true", help="skip the 4096 x N=4096 strong-scaling side measurement (about 16 s on one GPU)")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launcher even with --gpus 1 (a one-rank RCCL job)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE for a one-GPU box (never a default; PGM_BENCH_SHARE_GPU=1 does the same): all --gpus N ranks use device 0 and talk "
+                         "over gloo with the log-likelihoods staged through host memory -- the HIP path in N processes of one job; refused when "
+                         "two or more devices are visible")
     args = ap.parse_args()
+    share = args.share_gpu or os.environ.get("PGM_BENCH_SHARE_GPU") == "1" or os.environ.get(launch.SHARE_VAR) == "1"
 
     if not launch.under_a_launcher() and (args.gpus > 1 or args.spawn):
         # parent only: nothing here touches a GPU -- the devices are counted from the kernel driver's topology files and the
         # *_VISIBLE_DEVICES variables, not through the HIP runtime (None = unknown: the ranks then report what they find)
         sys.exit(launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
-                                    visible_devices=launch.visible_gpu_count()))
+                                    visible_devices=launch.visible_gpu_count(), share_gpu=share))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it plainly, or with --nproc-per-node {args.gpus})")
+    if share:
+        if torch.cuda.device_count() != 1:
+            sys.exit(f"bench.py: --share-gpu is the one-GPU test mode, {torch.cuda.device_count()} devices visible")
+        local = 0                                                # every rank on the one device
     if not torch.cuda.is_available() or local >= torch.cuda.device_count():
         sys.exit(f"bench.py: rank {rank} needs GPU {local}, {torch.cuda.device_count()} visible (there is no CPU fallback)")
     torch.cuda.set_device(local)
@@ -460,8 +485,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if share:       # RCCL cannot put two ranks on one device: gloo, values staged through host memory (pgmuvi_amd.batch)
+            dist.init_process_group("gloo", init_method=launch.init_method_of(), rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", init_method=launch.init_method_of(), device_id=dev, rank=rank, world_size=world)
     h = Harness(dev, world)
+    par_note = (f"TEST MODE --share-gpu: {world} ranks on ONE device over gloo (host-staged gather) -- exercises the multi-process path, "
+                f"not a scaling measurement; " if share else "")
     n = args.n
     metric = "marginal-log-likelihood evals/sec, N=4096 Q=4 SM kernel" if n == 4096 else f"marginal-log-likelihood evals/sec, N={n} Q=4 SM kernel"
 
@@ -477,7 +507,7 @@ def main():
                 "config": {"workload": f"cfg3-style batch: {total} independent 1-D light curves N={n}, Q=4 spectral-mixture exact GP, fp64, "
                                        f"value + full gradient, the whole batch per step", "total_batch": total, "n": n, "q": 4, "d": 1,
                            "light_curves_per_gpu": res["light_curves_per_gpu"], "chunk": res["chunk"],
-                           "parallelism": f"block partition of the batch over {world} GPU(s), one all_gather of the {total} log-liks per step"},
+                           "parallelism": par_note + f"block partition of the batch over {world} GPU(s), one all_gather of the {total} log-liks per step"},
                 "whole_evaluation": {"algorithmic_flops_per_eval": float(n) ** 3, "tflops_per_gpu": res["algorithmic_tflops_per_gpu"],
                                      "frac_of_fp64_mfma_peak": res["algorithmic_frac_of_fp64_mfma_peak"]},
             }
@@ -538,7 +568,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cfg2: 1-D light curve N={n}, Q=4 spectral-mixture exact GP, fp64, value + full gradient, "
                                    f"{B} light curve(s) per GPU per step", "batch_per_gpu": B, "n": n, "q": 4, "d": 1,
-                       "parallelism": f"independent light curves per GPU x{world}, all_gather of log-liks per step"},
+                       "parallelism": par_note + (f"independent light curves per GPU x{world}, all_gather of log-liks per step" if world == 1 else
+                                       f"ONE light curve per GPU x{world}: a ~2 ms evaluation then a blocking all_gather with nothing to overlap it -- at N>1 "
+                                       f"this value measures collective latency per step; the multi-GPU figure is `strong_scaling` (top level of "
+                                       f"this line): one 512 x N=2048 and one 4096 x N=4096 batch sharded over the {world} GPUs")},
             "roofline": roofline,
             "roofline_build": roofline_build,
             "phase_ms_per_step": phases,
@@ -592,7 +625,7 @@ def main():
         # the same 512 light curves as they come in practice: unequal lengths (ragged N)
         ss["ragged_512_x_n1024_2048"] = ragged_run(h, 512, 1024, 2048, 3, 1, rank, world, dev)
         _hip.release_workspaces()
-        extra["strong_scaling"] = ss
+        extra["strong_scaling"] = ss                             # (top level of the line: `result.update(extra)` below)
         if world == 1:
             extra["reference_published_workload"] = reference_published_workload(dev)
             _hip.release_workspaces()
@@ -612,6 +645,12 @@ def main():
             result["cpu_baseline_all_cores"] = dict(cb, note="this process may use no more CPUs than the 16-thread figure already does")
     if rank == 0:
         result.update(extra)
+        if "strong_scaling" in extra:
+            # the driver's parser keeps `config`: the batch figures (whole job, all ranks) stand there too, beside the caveat
+            result["config"]["strong_scaling_evals_per_s"] = {k: v["evals_per_s"] for k, v in extra["strong_scaling"].items()}
+            dv = extra["strong_scaling"].get("cfg3_512_x_n2048", {}).get("max_abs_dev_vs_fixture")
+            if dv is not None:
+                result["config"]["cfg3_512_x_n2048_max_abs_dev_vs_fixture"] = dv
         print(json.dumps(result))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -41,11 +41,31 @@ const char* pgm_version(void);
 /* Largest Q*d the kernels are built for (LDS staging of per-point factors). */
 int pgm_max_qd(void);
 
+/* Most points one light curve may have: 16384 = 128 block rows of 128 (see below). */
+int64_t pgm_max_n(void);
+
 /*
  * Workspace: every device buffer the path needs for `max_batch` simultaneous
  * problems of up to `max_n` points (factor matrix, diagonal-block inverses,
  * per-point factors, partial sums).  Allocated once, reused by every call.
  * `max_d` in {1,2}; `max_q * max_d <= pgm_max_qd()`.
+ *
+ * SIZE CONTRACT.  1 <= max_n <= pgm_max_n() = 16384; anything else returns -3
+ * before a device is touched.  Up to 64 block rows (N <= 8192) one light curve
+ * runs the fused sweep (its launch plans are 64-bit row masks; 41-64 block rows:
+ * in windows); from 65 block rows on (N = 8193 .. 16384) the panel sweep takes
+ * over -- the schedule of large batches, applied to the one matrix -- with the
+ * same kernels, results and error reporting.  Both sides of that boundary and
+ * the upper end are held to committed oracle fixtures at 1e-9 (value) / 1e-7
+ * (gradients): N = 8192 (config 4), 8320 and 16384 (tests/golden,
+ * tests/test_gpu_parity.py).  Larger matrices are refused rather than run
+ * untested: nothing in the index arithmetic stops at 16384 (tile addresses are
+ * 64-bit), but no parity value exists beyond it, and the reference itself does
+ * not go there -- its exact GPs "scale to datasets of up to ~1000 points"
+ * (/root/reference/paper/paper.md:144; Lightcurve subsamples to max_samples,
+ * pgmuvi/lightcurve.py:1733).
+ * Memory: about 9.2 * max_np^2 bytes per problem, max_np = max_n rounded up to
+ * 128 (2.5 GB at 16384).
  */
 int pgm_workspace_create(pgm_ws** ws, int device, int64_t max_n, int max_q, int max_d, int max_batch);
 int pgm_workspace_destroy(pgm_ws* ws);

@@ -30,10 +30,10 @@ reference's own ``fit_LS`` on the astropy-shaped shim): the comparison notebook'
 from the reference's own phase-scramble bootstrap over the periodogram, because a band selected from a 2-D light curve
 stays on the multiband code path -- the analytic 'davies' / 'baluev' / 'single' formulas below remain unverified); the
 ``use_best_band_init=True`` periodogram's peak period / height / prominence (149.170715 / 0.992789 / 0.859738, cell 20).
-**Not reproduced**: the *default multiband* numbers of that cell (height 0.909449, prominence 0.579050): the
-chi^2-weighted "fast" multiband form restated in ``multiband_fast`` gives 0.984977 / 0.824881, and so do a restated
-'flexible' form and every weighting tried (tools notes in DESIGN.md section 5) -- the multiband combination stays
-unverified.  Independent known-answer check available here: the
+The *default multiband* numbers of that cell (height 0.909449, prominence 0.579050, area fraction 0.016485) and the eight
+peaks of the two-period cell are reproduced too (round 6) -- by weighting the per-band periodograms with the sum of their
+own squared powers, which is what astropy's 'fast' multiband method does (``multiband_fast``); the published chi^2 weights
+give 0.984977 / 0.824881.  Independent known-answer check available here: the
 periodogram is 1 - chi^2(f)/chi^2_ref of an explicit weighted least-squares fit (``numpy.linalg.lstsq``).
 
 Only ``tests/`` may import this module.
@@ -160,8 +160,34 @@ def power_auto(t, y, dy, freq, fit_mean=True, center_data=True):
 
 
 def multiband_fast(t, y, bands, dy, freq, fit_mean=True, center_data=True, sb_auto=False):
-    """Multiband periodogram, "fast" form (VanderPlas & Ivezic 2015; what ``pgmuvi/multiband_ls_significance.py:51-106`` asks
-    astropy for): per-band standard-normalised powers weighted by each band's reference chi^2 about its weighted mean."""
+    """Multiband periodogram, "fast" form, AS ASTROPY COMPUTES IT (what ``pgmuvi/multiband_ls_significance.py:51-106, 202`` asks
+    for: ``LombScargleMultiband(t, y, bands, dy=dy).power(freq, method='fast')``): one standard-normalised floating-mean
+    periodogram per band, combined with the weights
+
+        weight[b] = sum_f P_b(f)^2 / sum_b' sum_f P_b'(f)^2
+
+    -- the sum of the band's own SQUARED POWERS over the frequency grid.  The published method (VanderPlas & Ivezic 2015;
+    gatspy's ``LombScargleMultibandFast``) weights by each band's reference chi^2; astropy's port keeps that line's shape but
+    applies it to what its per-band call returns, which is the power array (``mbfast_impl.lombscargle_mbfast``: "Total score
+    is the sum of powers weighted by chi2-normalization").  Settled by the reference's recorded outputs, not by reading astropy
+    (not installed here): with these weights the Lomb-Scargle notebook's default multiband cell reproduces to the printed
+    digit -- height 0.909449 (0.9094498 here), prominence 0.579050 (0.579052), area fraction 0.016485 (0.016482), all eight
+    peak frequencies of the two-period cell in the recorded order -- while the chi^2 weights give 0.984977 / 0.824881
+    (``docs/source/notebooks/PGMUVI_Lomb_Scargle.ipynb:893-903``; ``multiband_chi2_weighted`` below keeps that form)."""
+    t = np.asarray(t, dtype=float); y = np.asarray(y, dtype=float); bands = np.asarray(bands)
+    powers = []
+    for b in np.unique(bands):
+        m = bands == b
+        dyb = None if dy is None else np.asarray(dy, dtype=float)[m]
+        powers.append((power_auto if sb_auto else power)(t[m], y[m], dyb, freq, fit_mean, center_data))
+    powers = np.asarray(powers)
+    wgt = np.sum(powers ** 2, axis=1)
+    return np.dot(wgt / wgt.sum(), powers)
+
+
+def multiband_chi2_weighted(t, y, bands, dy, freq, fit_mean=True, center_data=True, sb_auto=False):
+    """The published form (per-band powers weighted by each band's reference chi^2 about its weighted mean) -- NOT what the
+    reference's recorded numbers contain (see ``multiband_fast``); kept so that the test of the recorded cell can show both."""
     t = np.asarray(t, dtype=float); y = np.asarray(y, dtype=float); bands = np.asarray(bands)
     chi2_0, powers = [], []
     for b in np.unique(bands):

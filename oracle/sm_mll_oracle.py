@@ -250,6 +250,80 @@ def mll_value_grad_closed_form(x, y, mean, noise, w, mu, v, dim_order=0, jitter=
         return val, dict(w=g_w, mu=g_mu.reshape(mu.shape), v=g_v.reshape(v.shape), noise=g_noise, mean=g_mean)
 
 
+def mll_value_grad_closed_form_blocked(x, y, mean, noise, w, mu, v, dim_order=0, jitter=0.0, rows=512):
+    """:func:`mll_value_grad_closed_form` with the (Q,N,N,d) intermediates cut into blocks of ``rows`` matrix rows, so
+    that the BASELINE sizes the dense form cannot hold in this container's memory (config 4: N=8192, d=2, Q=3) have an
+    oracle value too.  Same formulas term by term; the matrix, its Cholesky factor and its inverse are still dense
+    N x N (``torch.linalg``), only the kernel build and the gradient contraction run block row by block row, each
+    block's partial sums added in row order.  ``tests/test_oracle.py`` holds it to the dense form."""
+    with torch.no_grad():
+        x2 = _as_2d(x)
+        n, d = x2.shape
+        Q = w.shape[0]
+        mu2 = mu.reshape(Q, d)
+        v2 = v.reshape(Q, d)
+        wq = w.view(Q, 1, 1, 1)
+
+        def parts(lo, hi):
+            xs = x2.unsqueeze(0) * v2.unsqueeze(1)                      # (Q,N,d)
+            xc = x2.unsqueeze(0) * mu2.unsqueeze(1)
+            ds = xs[:, lo:hi].unsqueeze(2) - xs.unsqueeze(1)            # (Q,r,N,d)
+            dc = TWO_PI * (xc[:, lo:hi].unsqueeze(2) - xc.unsqueeze(1))
+            return torch.exp(-TWO_PI_SQ * ds ** 2), torch.cos(dc), torch.sin(dc)
+
+        A = torch.empty(n, n, dtype=x2.dtype)
+        for lo in range(0, n, rows):
+            hi = min(n, lo + rows)
+            e, c, _ = parts(lo, hi)
+            A[lo:hi] = (wq * e * c).sum(0).prod(-1) if dim_order == 0 else (w.view(Q, 1, 1) * (e * c).prod(-1)).sum(0)
+        nd = _noise_diag(torch.as_tensor(noise, dtype=x2.dtype), n)
+        A.diagonal().add_(nd + jitter)
+        L = torch.linalg.cholesky(A)
+        del A
+        r = (y - torch.as_tensor(mean, dtype=x2.dtype).expand(n)).reshape(n, 1)
+        z = torch.linalg.solve_triangular(L, r, upper=False)
+        val = -0.5 * ((z * z).sum() + 2.0 * torch.log(torch.diagonal(L)).sum() + n * LOG_2PI) / n
+        alpha = torch.cholesky_solve(r, L)
+        G = torch.cholesky_inverse(L)
+        del L
+        G.neg_().addmm_(alpha, alpha.T)                                 # G = alpha alpha^T - A^-1
+        half_n = 0.5 / n
+        g_w = torch.zeros_like(w)
+        g_mu = torch.zeros_like(mu2)
+        g_v = torch.zeros_like(v2)
+        for lo in range(0, n, rows):
+            hi = min(n, lo + rows)
+            e, c, s = parts(lo, hi)
+            tau = x2[lo:hi].unsqueeze(1) - x2.unsqueeze(0)              # (r,N,d)
+            Gb = G[lo:hi].unsqueeze(0)                                  # (1,r,N)
+            ec = e * c
+            S = (wq * ec).sum(0) if dim_order == 0 else None            # (r,N,d)
+            for k in range(d):
+                if dim_order == 0:
+                    oth = torch.ones_like(S[..., 0])
+                    for kk in range(d):
+                        if kk != k:
+                            oth = oth * S[..., kk]
+                    oth = oth.unsqueeze(0)
+                    g_w += half_n * (Gb * oth * ec[..., k]).sum((1, 2))
+                else:
+                    oth = torch.ones_like(ec[..., 0])
+                    for kk in range(d):
+                        if kk != k:
+                            oth = oth * ec[..., kk]
+                dmu_k = -TWO_PI * tau[..., k] * wq[..., 0] * e[..., k] * s[..., k]
+                dv_k = -2.0 * TWO_PI_SQ * v2[:, k].view(Q, 1, 1) * tau[..., k] ** 2 * wq[..., 0] * ec[..., k]
+                g_mu[:, k] += half_n * (Gb * oth * dmu_k).sum((1, 2))
+                g_v[:, k] += half_n * (Gb * oth * dv_k).sum((1, 2))
+            if dim_order != 0:
+                g_w += half_n * (Gb * ec.prod(-1)).sum((1, 2))
+        g_noise_vec = half_n * torch.diagonal(G)
+        noise_t = torch.as_tensor(noise)
+        g_noise = g_noise_vec.sum().reshape(noise_t.shape) if noise_t.numel() == 1 else g_noise_vec.reshape(noise_t.shape)
+        g_mean = (alpha / n).reshape(n)
+        return val, dict(w=g_w, mu=g_mu.reshape(mu.shape), v=g_v.reshape(v.shape), noise=g_noise, mean=g_mean)
+
+
 # --------------------------------------------------------------------------
 # section 8f row 1: posterior prediction (eval mode), dense Cholesky semantics
 # (pgmuvi/lightcurve.py:9607-9631: likelihood(model(x_test)))

@@ -22,6 +22,7 @@ _lock = threading.Lock()
 SYMBOLS = {
     "pgm_version": (c_char_p, []),
     "pgm_max_qd": (c_int, []),
+    "pgm_max_n": (c_int64, []),
     "pgm_workspace_create": (c_int, [POINTER(c_void_p), c_int, c_int64, c_int, c_int, c_int]),
     "pgm_workspace_destroy": (c_int, [c_void_p]),
     "pgm_workspace_bytes": (c_size_t, [c_void_p]),
@@ -106,6 +107,11 @@ def max_qd() -> int:
     return int(load().pgm_max_qd())
 
 
+def max_n_limit() -> int:
+    """Most points one light curve may have (include/pgmuvi_hip.h: the size contract)."""
+    return int(load().pgm_max_n())
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else c_void_p(t.data_ptr())
 
@@ -139,6 +145,9 @@ class Workspace:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.key = (idx, max_n, max_q, max_d, max_batch)
         handle = c_void_p()
+        if max_n > max_n_limit():
+            raise RuntimeError(f"a light curve of {max_n} points: the HIP library takes at most {max_n_limit()} (128 block rows of 128; the "
+                               "largest size held to an oracle fixture, include/pgmuvi_hip.h) -- pgm_workspace_create would return -3")
         _check(lib.pgm_workspace_create(byref(handle), idx, max_n, max_q, max_d, max_batch), "pgm_workspace_create")
         self.handle = handle
         self.max_n, self.max_q, self.max_d, self.max_batch = max_n, max_q, max_d, max_batch

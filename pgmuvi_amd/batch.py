@@ -232,12 +232,21 @@ def sharded_ragged_step(shard: Dict[str, object], need_grad=True, chunk: Optiona
     return out, gather_by_owner(local, shard["owner"], group=group)
 
 
+def _staged_on_host(local: torch.Tensor, group=None) -> bool:
+    """Device values over a process group that has no device collectives (``gloo``: the test-only mode in which several ranks
+    share ONE GPU, ``bench.py --share-gpu``; RCCL cannot put two ranks on one device): the few KB of log-likelihoods go
+    through host memory for the collective and come back to the device afterwards.  Never the case on RCCL ("nccl")."""
+    return local.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def gather_by_owner(local: torch.Tensor, owner: Sequence[int], group=None) -> torch.Tensor:
     """all_gather of per-curve values when light curve i lives on rank owner[i] (each rank holds its own in ascending i):
     one collective of equal-sized padded buffers, then every value goes to its place in the batch's order."""
     total = len(owner)
     if not (dist.is_available() and dist.is_initialized()):
         return local
+    if _staged_on_host(local, group):
+        return gather_by_owner(local.cpu(), owner, group=group).to(local.device)
     world = dist.get_world_size(group)
     index = [[i for i in range(total) if owner[i] == r] for r in range(world)]
     width = max(1, max(len(ix) for ix in index))
@@ -316,6 +325,8 @@ def gather_logliks(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     one length-``total`` vector, identical on every rank.  Single process: identity."""
     if not (dist.is_available() and dist.is_initialized()):
         return local
+    if _staged_on_host(local, group):
+        return gather_logliks(local.cpu(), total, group=group).to(local.device)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
     if all(c == counts[0] for c in counts):

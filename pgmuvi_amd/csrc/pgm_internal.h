@@ -7,6 +7,7 @@
 
 constexpr int PGM_MAX_QD = 16;      // Q*d the LDS staging is sized for
 constexpr int PGM_MAX_D = 2;
+constexpr int64_t PGM_MAX_N = 16384;   // points per light curve (128 block rows): the largest size held to an oracle fixture (include/pgmuvi_hip.h)
 constexpr int CRIT_MAX = 48;      // light curves per call the fused sweep is ever used for (batch x block rows <= 128, >= 3 block rows)
 
 // A composed stationary kernel as a sum of products of leaf kernels (pgm_generic.inc); mirrors pgm_kernel_program of the

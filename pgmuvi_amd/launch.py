@@ -19,6 +19,8 @@ import signal
 import socket
 import subprocess
 import sys
+import shutil
+import tempfile
 import threading
 import time
 from typing import Dict, List, Optional, Sequence
@@ -82,33 +84,62 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def rank_environment(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
-    """Environment of rank ``rank`` of a one-node job of ``world`` ranks (one rank per GPU: LOCAL_RANK == RANK)."""
+INIT_VAR = "PGM_LAUNCH_INIT"       # rendezvous of a job started by spawn_ranks: a file:// URL in a directory the parent made
+SHARE_VAR = "PGM_SHARE_GPU"        # "1": test-only job whose ranks all use device 0 over gloo (bench.py --share-gpu)
+
+
+def rank_environment(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None,
+                     init_method: Optional[str] = None, share_gpu: bool = False) -> Dict[str, str]:
+    """Environment of rank ``rank`` of a one-node job of ``world`` ranks (one rank per GPU: LOCAL_RANK == RANK).
+    ``init_method``: the job's rendezvous (``file://...``; :func:`init_method_of` hands it to ``init_process_group``) -- a
+    path only this job knows, where ``MASTER_PORT`` is a port number found free a moment ago that anybody may have taken since."""
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # the host driver only supports dmabuf IPC (RCCL needs it)
     env[CHILD_MARK] = "1"
+    if init_method:
+        env[INIT_VAR] = init_method
+    else:
+        env.pop(INIT_VAR, None)
+    if share_gpu:
+        env[SHARE_VAR] = "1"
     return env
 
 
+def init_method_of(env=None) -> Optional[str]:
+    """What a rank passes as ``init_process_group(init_method=...)``: the launcher's file rendezvous when :func:`spawn_ranks`
+    started it, None (= ``env://``: MASTER_ADDR / MASTER_PORT) under torch.distributed.run."""
+    env = os.environ if env is None else env
+    return env.get(INIT_VAR) or None
+
+
 def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] = None, grace_s: float = 15.0,
-                out=None, err=None) -> int:
+                out=None, err=None, share_gpu: bool = False) -> int:
     """Runs ``argv`` (a full command line, e.g. ``[sys.executable, "bench.py", "--gpus", "4", ...]``) once per rank and
     waits.  Rank 0's stdout is relayed line by line to ``out`` (default: this process's stdout); the other ranks' stdout goes
     to ``err`` with everybody's stderr.  Returns 0 when every rank returned 0, otherwise the first non-zero status seen (a
     rank that fails takes the others down after ``grace_s`` seconds: they would wait in a collective for ever).
     ``visible_devices``: refuse (status 2, one line on ``err``) when fewer devices than ranks are visible; None = no check
-    (CPU jobs on gloo)."""
+    (CPU jobs on gloo).  ``share_gpu`` (TEST MODE, never a default): every rank uses device 0 and the ranks talk over gloo --
+    the way a one-GPU box runs the HIP path in several processes of one job; refused when two or more devices are visible
+    (then one rank per GPU over RCCL is the job to run) or none is."""
     out = sys.stdout if out is None else out
     err = sys.stderr if err is None else err
     if world < 1:
         print(f"launch: {world} ranks requested", file=err)
         return 2
-    if visible_devices is not None and visible_devices < world:
+    if share_gpu:
+        if visible_devices is not None and visible_devices != 1:
+            print(f"launch: --share-gpu is the one-GPU test mode, this host shows {visible_devices} GPUs"
+                  + (" (run one rank per GPU instead)" if visible_devices > 1 else ""), file=err)
+            return 2
+    elif visible_devices is not None and visible_devices < world:
         print(f"launch: --gpus {world} needs {world} visible GPUs, this host shows {visible_devices}", file=err)
         return 2
-    port = free_port()                                         # (closed before rank 0 binds it: a small window another process could take it in)
+    port = free_port()                                         # (MASTER_PORT for code that insists on env://; the ranks meet through the file below)
+    rdzv_dir = tempfile.mkdtemp(prefix="pgm_launch_")
+    init_method = "file://" + os.path.join(rdzv_dir, "rendezvous")
     procs: List[subprocess.Popen] = []
     try:
         child_err = err.fileno()                               # (a real descriptor: the children write to it directly)
@@ -141,7 +172,7 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
                 pass
     try:
         for r in range(world):
-            procs.append(subprocess.Popen(list(argv), env=rank_environment(r, world, port),
+            procs.append(subprocess.Popen(list(argv), env=rank_environment(r, world, port, init_method=init_method, share_gpu=share_gpu),
                                           stdout=subprocess.PIPE if r == 0 else (child_err if child_err is not None else 2),
                                           stderr=child_err, text=(r == 0)))
         # rank 0's lines are relayed as they come (it prints little: the JSON line at the end) by a reader thread, so that
@@ -203,6 +234,7 @@ def spawn_ranks(argv: Sequence[str], world: int, visible_devices: Optional[int] 
                 p.wait(timeout=10)
             except Exception:
                 pass
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
         for sg, h in previous.items():
             try:
                 signal.signal(sg, h)

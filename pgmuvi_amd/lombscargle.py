@@ -154,10 +154,12 @@ class LombScargle:
 
 class LombScargleMultiband:
     """``astropy.timeseries.LombScargleMultiband`` as pgmuvi uses it (``pgmuvi/multiband_ls_significance.py:51-106``, always with
-    ``method='fast'``): the multiband periodogram of VanderPlas & Ivezic (2015) in its "fast" form -- one floating-mean
-    Lomb-Scargle periodogram per band (the HIP kernel, one call per band), combined with weights
-    ``chi2_0[b] / sum(chi2_0)`` where ``chi2_0[b] = sum(((y - ybar_w) / dy)**2)`` over band b.  Restated from the published
-    method and gatspy's / astropy's description of it; astropy itself is not available here to compare against.  The
+    ``method='fast'``): one floating-mean Lomb-Scargle periodogram per band (the HIP kernel, one call per band), combined
+    with the weights astropy's 'fast' multiband method uses -- ``sum_f P_b(f)**2`` of each band's own periodogram over the
+    frequency grid, normalised over the bands (NOT the reference chi^2 of the published method, VanderPlas & Ivezic 2015).
+    Pinned by the reference's recorded outputs: the Lomb-Scargle notebook's default multiband cell (height 0.909449,
+    prominence 0.579050) and the eight peaks of its two-period cell reproduce to the printed digits through the reference's
+    own ``fit_LS`` (``tests/test_dropin_reference.py``; ``docs/source/notebooks/PGMUVI_Lomb_Scargle.ipynb:893-903``).  The
     'flexible' method (a regularised multi-term model fit) is not implemented."""
 
     def __init__(self, t, y, bands, dy=None, normalization="standard", nterms_base=1, nterms_band=1, reg_base=None,
@@ -183,16 +185,14 @@ class LombScargleMultiband:
         if normalization not in (None, "standard"):
             raise NotImplementedError("only normalization='standard'")
         f = np.asarray(_np(frequency), dtype=np.float64)
-        chi2_0, powers = [], []
+        powers = []
         for band in np.unique(self.bands):
             m = self.bands == band
             dyb = None if self.dy is None else self.dy[m]
-            w = np.ones(int(m.sum())) if dyb is None else dyb ** -2.0
-            yb = self.y[m]
-            chi2_0.append(float(np.sum(w * (yb - np.dot(w, yb) / w.sum()) ** 2)))
-            powers.append(LombScargle(self.t[m], yb, dyb, fit_mean=self.fit_mean, center_data=self.center_data).power(f.reshape(-1), method=sb_method))
-        chi2_0 = np.asarray(chi2_0)
-        return np.dot(chi2_0 / chi2_0.sum(), np.asarray(powers)).reshape(f.shape)
+            powers.append(LombScargle(self.t[m], self.y[m], dyb, fit_mean=self.fit_mean, center_data=self.center_data).power(f.reshape(-1), method=sb_method))
+        powers = np.asarray(powers)
+        wgt = np.sum(powers ** 2, axis=1)                        # (astropy's weights: each band's summed squared power)
+        return np.dot(wgt / wgt.sum(), powers).reshape(f.shape)
 
     def autopower(self, method="flexible", sb_method="auto", normalization="standard", samples_per_peak=5, nyquist_factor=5,
                   minimum_frequency=None, maximum_frequency=None):

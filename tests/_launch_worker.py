@@ -25,8 +25,9 @@ def main():
     import torch
     import torch.distributed as dist
     import _oracle_backend as ob
+    from pgmuvi_amd import launch
     from pgmuvi_amd.batch import make_shard, sharded_batch_step
-    dist.init_process_group("gloo", rank=rank, world_size=world)   # MASTER_ADDR / MASTER_PORT from the launcher
+    dist.init_process_group("gloo", init_method=launch.init_method_of(), rank=rank, world_size=world)   # the launcher's file rendezvous
     shard = make_shard(args.total_batch, rank, world, args.npoints, "cfg3")
     out, ll = sharded_batch_step(shard, args.total_batch, 2, _compute=ob.mll_value_grad)
     seen = [None] * world
@@ -34,7 +35,7 @@ def main():
     dist.barrier()
     if rank == 0:
         print(json.dumps({"world": world, "gpus_arg": args.gpus, "ranks": seen, "loglik": ll.tolist(),
-                          "master": [os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"]], "child_mark": os.environ.get("PGM_LAUNCH_CHILD")}))
+                          "master": [os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"]], "init": launch.init_method_of(), "child_mark": os.environ.get("PGM_LAUNCH_CHILD")}))
     dist.destroy_process_group()
 
 

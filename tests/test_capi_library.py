@@ -46,6 +46,20 @@ def test_ctypes_table_matches_header():
     assert "trailing_update" in names and "diag_block" in names
 
 
+def test_size_contract_is_an_argument_check():
+    """include/pgmuvi_hip.h's size contract: 1 <= max_n <= pgm_max_n() = 16384 (128 block rows); anything else is refused
+    with -3 BEFORE a device is touched (so it can be checked here, without a GPU), and the Python binding says why."""
+    lib = _hip.load()
+    assert _hip.max_n_limit() == 16384
+    h = ctypes.c_void_p()
+    for bad in (0, -5, 16385, 1 << 20, 1 << 40):
+        assert lib.pgm_workspace_create(ctypes.byref(h), 0, bad, 4, 1, 1) == -3 and not h.value
+    with pytest.raises(RuntimeError, match="at most 16384"):
+        _hip.Workspace("cuda:0", 16385, 4, 1, 1)
+    txt = open(HEADER).read()
+    assert "SIZE CONTRACT" in txt and "pgm_max_n() = 16384" in txt and "paper/paper.md:144" in txt
+
+
 def test_code_object_is_gfx950_only():
     blob = open(_hip.lib_path(), "rb").read()
     assert b"gfx950" in blob

@@ -23,6 +23,38 @@ from pgmuvi_amd.batch import (balanced_assignment, default_chunk, evaluate_batch
 B, N = 5, 40
 
 
+def _rank_main(target, rank, world, init, outdir, args):
+    """Body of one gloo rank: stderr into a file of its own (shown by the parent when the rank fails), rendezvous through a
+    file only this job knows (no port to lose to another process between finding it free and binding it), the result as a
+    file -- nothing of the rank has to outlive it in a queue."""
+    err = os.open(os.path.join(outdir, f"rank{rank}.err"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    os.dup2(err, 2)
+    dist.init_process_group("gloo", init_method=init, rank=rank, world_size=world)
+    res = target(rank, world, *args)
+    torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ranks(target, world, *args, tmp_path):
+    """``world`` fresh gloo processes running ``target(rank, world, *args)``; returns their results in rank order."""
+    init = f"file://{tmp_path}/rendezvous"
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_main, args=(target, r, world, init, str(tmp_path), args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    bad = [(r, p.exitcode) for r, p in enumerate(procs) if p.exitcode != 0]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    if bad:
+        logs = "\n".join(f"--- rank {r} (exit {rc}) stderr:\n" + open(os.path.join(str(tmp_path), f"rank{r}.err")).read()[-3000:] for r, rc in bad)
+        raise AssertionError(f"ranks failed: {bad}\n{logs}")
+    return [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(world)]
+
+
 def _batch():
     xs, ys, ns, ws, mus, vs, ms = [], [], [], [], [], [], []
     for i in range(B):
@@ -33,11 +65,8 @@ def _batch():
     return tuple(torch.stack(L) for L in (xs, ys, ms, ns, ws, mus, vs))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world):
     import _oracle_backend as ob
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     x, y, m, nz, w, mu, v = _batch()
     lo, hi = shard_bounds(B, rank, world)
     out = evaluate_batch(x[lo:hi], y[lo:hi], m[lo:hi], nz[lo:hi], w[lo:hi], mu[lo:hi], v[lo:hi], _compute=ob.mll_value_grad)
@@ -45,25 +74,12 @@ def _worker(rank, world, port, q):
     gw = gather_logliks(out["g_w"], B)
     eq = gather_logliks(torch.full((2, 3), float(rank), dtype=torch.float64), 2 * world)   # equal shards: single-collective path
     assert eq.shape == (2 * world, 3) and eq[:, 0].tolist() == [float(r) for r in range(world) for _ in range(2)]
-    q.put((rank, ll, gw))
-    dist.barrier()
-    dist.destroy_process_group()
+    return rank, ll, gw
 
 
-def test_world_size_2_shard_and_gather_equals_single_process():
+def test_world_size_2_shard_and_gather_equals_single_process(tmp_path):
     import _oracle_backend as ob
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=300) for _ in range(2)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    got = _run_ranks(_worker, 2, tmp_path=tmp_path)
     x, y, m, nz, w, mu, v = _batch()
     full = evaluate_batch(x, y, m, nz, w, mu, v, _compute=ob.mll_value_grad)
     for rank, ll, gw in got:
@@ -71,38 +87,22 @@ def test_world_size_2_shard_and_gather_equals_single_process():
         assert torch.equal(gw, full["g_w"])
 
 
-def _strong_worker(rank, world, port, q, total, n, chunk):
+def _strong_worker(rank, world, total, n, chunk):
     """The code path of ``bench.py --total-batch`` (``make_shard`` + ``sharded_batch_step``) with the oracle stand-in."""
     import _oracle_backend as ob
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     shard = make_shard(total, rank, world, n, "cfg3")
     out, ll = sharded_batch_step(shard, total, chunk, _compute=ob.mll_value_grad)
-    q.put((rank, shard["y"].shape[0], ll, out.get("g_mu")))
-    dist.barrier()
-    dist.destroy_process_group()
+    return rank, shard["y"].shape[0], ll, out.get("g_mu")
 
 
 @pytest.mark.parametrize("total,world", [(7, 2), (2, 3)])
-def test_strong_scaling_step_is_independent_of_the_partition(total, world):
+def test_strong_scaling_step_is_independent_of_the_partition(total, world, tmp_path):
     """A ``total``-light-curve batch evaluated by ``world`` ranks (block partition, chunks of 2 with a ragged tail, one
     all_gather) gives every rank the same vector as one process evaluating the whole batch -- also when shards are unequal
     (7 over 2) or empty (2 over 3)."""
     import _oracle_backend as ob
     n = 48
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q, total, n, 2)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda g: g[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    got = _run_ranks(_strong_worker, world, total, n, 2, tmp_path=tmp_path)
     whole = make_shard(total, 0, 1, n, "cfg3")
     ref, ref_ll = sharded_batch_step(whole, total, None, _compute=ob.mll_value_grad)       # single process: no collective
     assert torch.equal(ref_ll, ref["mll"]) and ref_ll.shape == (total,)
@@ -115,39 +115,23 @@ def test_strong_scaling_step_is_independent_of_the_partition(total, world):
     assert default_chunk(2048) == 512 and default_chunk(4096) == 256 and 1 <= default_chunk(16384) <= 16
 
 
-def _ragged_worker(rank, world, port, q, total, n_lo, n_hi):
+def _ragged_worker(rank, world, total, n_lo, n_hi):
     """Ragged batch: light curves dealt to the ranks by N^3 (``make_ragged_shard``), each rank evaluates its own through the
     ragged entry point (oracle stand-in), one all_gather puts the values back into the batch's order."""
     import _oracle_backend as ob
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     shard = make_ragged_shard(total, rank, world, n_lo, n_hi)
     out, ll = sharded_ragged_step(shard, chunk=3, _compute=ob.mll_value_grad_ragged)
-    q.put((rank, shard["index"], ll, out.get("g_w"), [g.clone() for g in out.get("g_noise", [])]))
-    dist.barrier()
-    dist.destroy_process_group()
+    return rank, shard["index"], ll, out.get("g_w"), [g.clone() for g in out.get("g_noise", [])]
 
 
 @pytest.mark.parametrize("total,world", [(7, 2), (2, 3)])
-def test_ragged_batch_over_ranks_is_the_single_process_result(total, world):
+def test_ragged_batch_over_ranks_is_the_single_process_result(total, world, tmp_path):
     """Unequal N across ranks: ``balanced_assignment`` on N^3 decides who evaluates what, every rank
     ends with the same vector of log-likelihoods in the batch's order as one process evaluating everything -- also with a
     rank that owns nothing (2 light curves over 3 ranks)."""
     import _oracle_backend as ob
     n_lo, n_hi = 24, 70
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q, total, n_lo, n_hi)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda g: g[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    got = _run_ranks(_ragged_worker, world, total, n_lo, n_hi, tmp_path=tmp_path)
     whole = make_ragged_shard(total, 0, 1, n_lo, n_hi)
     assert whole["index"] == list(range(total)) and whole["lengths"] == ragged_lengths(total, n_lo, n_hi)
     assert len(set(whole["lengths"])) > 1                             # (ragged indeed)
@@ -237,6 +221,7 @@ def test_self_launcher_starts_one_rank_per_device_and_relays_rank_0():
     assert rc == 0
     got = json.loads([ln for ln in buf.getvalue().splitlines() if ln.startswith("{")][-1])
     assert got["world"] == 2 and got["gpus_arg"] == 2 and got["child_mark"] == "1" and got["master"][0] == "127.0.0.1"
+    assert got["init"].startswith("file://") and not os.path.exists(os.path.dirname(got["init"][7:]))   # met through a file of the job's own, gone now
     assert got["ranks"] == [[0, 0, 3], [1, 1, 2]]                 # rank == local rank, block partition 3 + 2
     whole = make_shard(total, 0, 1, n, "cfg3")
     _, ref = sharded_batch_step(whole, total, None, _compute=ob.mll_value_grad)
@@ -249,6 +234,14 @@ def test_self_launcher_starts_one_rank_per_device_and_relays_rank_0():
     err = io.StringIO()
     assert launch.spawn_ranks([sys.executable, "-c", "raise SystemExit(0)"], 2, visible_devices=1, err=err) == 2
     assert "needs 2 visible GPUs" in err.getvalue()
+    # the one-GPU test mode is refused where one rank per GPU is possible (and where there is no GPU at all)
+    for shown in (2, 8, 0):
+        err = io.StringIO()
+        assert launch.spawn_ranks([sys.executable, "-c", "raise SystemExit(0)"], 2, visible_devices=shown, err=err, share_gpu=True) == 2
+        assert "--share-gpu is the one-GPU test mode" in err.getvalue()
+    env = launch.rank_environment(1, 2, 1, base={}, init_method="file:///x/y", share_gpu=True)
+    assert env[launch.INIT_VAR] == "file:///x/y" and env[launch.SHARE_VAR] == "1" and launch.init_method_of(env) == "file:///x/y"
+    assert launch.init_method_of({}) is None
     env = launch.rank_environment(3, 8, 12345, base={})
     assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "12345")
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and launch.under_a_launcher(env) and not launch.under_a_launcher({})

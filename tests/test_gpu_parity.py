@@ -53,10 +53,11 @@ def _hip_eval(dev, x, y, mean, noise, w, mu, v, order=0, noise_scalar=None, need
 
 
 @pytest.mark.parametrize("name", ["cfg1", "cfg2_n64", "cfg2_n200", "cfg2_n512", "cfg2_n4096",
-                                  "cfg4_n256_order0", "cfg4_n256_order1"])
+                                  "cfg4_n256_order0", "cfg4_n256_order1", "cfg4_n8192_order0", "cfg4_n8192_order1"])
 def test_golden_fixtures(dev, golden_dir, name):
     """Every committed fixture (inputs made with the reference's generator helpers,
-    expectations from the oracle), including the full-size config 2 (N=4096, Q=4)."""
+    expectations from the oracle), including the full-size config 2 (N=4096, Q=4) and the full-size
+    config 4 (8 bands x 1024 = 8192 points, d=2, Q=3, both dimension orders: value and EVERY gradient)."""
     exp = _load(golden_dir, f"expect_{name}.npz")
     tag = name.replace("_order0", "").replace("_order1", "")
     order = 1 if name.endswith("order1") else 0
@@ -941,6 +942,60 @@ def test_config3_per_gpu_shard_of_64(dev):
     assert torch.allclose(out["g_noise"], out24["g_noise"], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("n", [8320, 16384])
+def test_beyond_64_block_rows_vs_the_oracle_fixture(dev, golden_dir, n):
+    """include/pgmuvi_hip.h's size contract above N = 8192: 65 block rows (the first size the fused sweep's 64-bit plans do
+    not cover: the panel sweep on one matrix) and 128 block rows (pgm_max_n()), config 2's recipe, value and every gradient
+    against the committed oracle fixtures; one point more than pgm_max_n() is refused."""
+    import hashlib
+    exp = _load(golden_dir, f"expect_cfg2_n{n}.npz")
+    t, y, e = syn.cfg2(n_obs=n)
+    sha = hashlib.sha256()
+    for a in (t, y, e):
+        sha.update(np.ascontiguousarray(a.numpy()).tobytes())
+    assert sha.digest() == exp["inputs_sha256"].tobytes()
+    w, mu, v = (torch.as_tensor(exp[f"{p}_0"]) for p in ("w", "mu", "v"))
+    out = _hip_eval(dev, t.double().reshape(n, 1), y.double(), torch.as_tensor(exp["meanc_0"]), e.double() ** 2, w, mu, v)
+    assert int(out["info"]) == 0
+    assert abs(float(out["mll"]) - float(exp["mll_0"])) < MLL_TOL
+    for p in ("w", "mu", "v", "noise", "mean"):
+        assert _rel(out[f"g_{p}"].reshape(-1), torch.as_tensor(exp[f"g_{p}_0"]).reshape(-1)) < GRAD_RTOL, p
+    out0 = _hip_eval(dev, t.double().reshape(n, 1), y.double(), torch.as_tensor(exp["meanc_0"]), e.double() ** 2, w, mu, v, need_grad=False)
+    assert float(out0["mll"]) == float(out["mll"])
+    _hip.release_workspaces()
+    if n == _hip.max_n_limit():
+        with pytest.raises(RuntimeError, match="at most 16384"):
+            _hip.Workspace(dev, n + 1, 4, 1, 1)
+
+
+def test_config3_at_its_stated_size_vs_the_oracle_fixture(dev, golden_dir):
+    """BASELINE config 3 whole: 512 light curves x N=2048, Q=4 through ``make_shard`` + ``sharded_batch_step`` (the code path of
+    ``bench.py --total-batch 512 --npoints 2048``) against the oracle's value of EVERY member and every gradient of members 0, 255
+    and 511 (``tests/golden/expect_cfg3_b512_n2048.npz``, ``make_golden.py --fullsize``).  The fixture also carries the SHA-256
+    of the 512 light curves as the reference's generator helpers made them: ``make_shard`` must produce exactly those."""
+    import hashlib
+    from pgmuvi_amd.batch import make_shard, sharded_batch_step
+    exp = _load(golden_dir, "expect_cfg3_b512_n2048.npz")
+    B, n = 512, 2048
+    sha = hashlib.sha256()
+    for i in range(B):
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=n)
+        assert per == float(exp["lead_period"][i])
+        for a in (t, y, e):
+            sha.update(np.ascontiguousarray(a.numpy()).tobytes())
+    assert sha.digest() == exp["inputs_sha256"].tobytes()
+    shard = make_shard(B, 0, 1, n, "cfg3", dev)
+    out, ll = sharded_batch_step(shard, B)
+    torch.cuda.synchronize()
+    assert ll.shape == (B,) and int(out["info"].abs().max()) == 0
+    dev_ = (ll.cpu() - torch.as_tensor(exp["mll"])).abs()
+    assert float(dev_.max()) < MLL_TOL, (int(dev_.argmax()), float(dev_.max()))
+    for i in (0, 255, 511):
+        for p_ in ("w", "mu", "v", "noise", "mean"):
+            assert _rel(out[f"g_{p_}"][i].reshape(-1), torch.as_tensor(exp[f"g_{p_}_{i}"]).reshape(-1)) < GRAD_RTOL, (p_, i)
+    _hip.release_workspaces()
+
+
 def test_lomb_scargle_kernel_vs_oracle(dev, golden_dir):
     """the periodogram kernel behind the astropy-shaped ``LombScargle`` against the numpy
     oracle -- the notebook's 89-point light curve (whose two highest peaks are the initial frequencies the reference
@@ -1017,11 +1072,30 @@ def test_lomb_scargle_notebook_recorded_peaks(dev, golden_dir):
     # (the recorded significance flags come from the reference's own phase-scramble bootstrap over this periodogram -- a band
     #  selected from a 2-D light curve keeps the multiband code path -- and are covered by tests/test_dropin_reference.py)
     assert float(ls.false_alarm_probability(pw.max(), method="davies")) < 0.05
-    # the multiband periodogram (per-band HIP periodograms, chi^2-weighted) equals the oracle's restatement of it
+    # the multiband periodogram (per-band HIP periodograms, weighted as astropy's 'fast' method weights them) equals the
+    # oracle's restatement of it ...
+    from scipy.signal import peak_prominences
     mb = L.LombScargleMultiband(t, y, wl, dy)
     fm = mb.autofrequency(nyquist_factor=5)
-    assert np.allclose(mb.power(fm, method="fast"), lso.multiband_fast(t, y, wl, dy, fm, sb_auto=True), rtol=1e-9, atol=1e-11)
+    pm = mb.power(fm, method="fast")
+    assert np.allclose(pm, lso.multiband_fast(t, y, wl, dy, fm, sb_auto=True), rtol=1e-9, atol=1e-11)
     assert np.allclose(mb.power(fm, method="fast", sb_method="slow"), lso.multiband_fast(t, y, wl, dy, fm), rtol=1e-9, atol=1e-12)
+    # ... and IS the reference's recorded default multiband periodogram (notebook cell 20: peak period 149.170715, height
+    # 0.909449, prominence 0.579050) -- the HIP kernel behind the number the reference holds
+    pkm, _ = find_peaks(pm)
+    km = pkm[np.argmax(pm[pkm])]
+    prom = peak_prominences(pm, pkm)[0][np.argmax(pm[pkm])]
+    rec_mb = p["nbmb_default"]
+    assert abs(1.0 / fm[km] - float(rec_mb[0])) < 1e-5 and abs(pm[km] - float(rec_mb[1])) < 2e-6 and abs(prom - float(rec_mb[2])) < 3e-6, \
+        (1.0 / fm[km], pm[km], prom)
+    # the two-period light curve with its densely sampled fourth band (cell 34): all eight recorded peaks, in the recorded order
+    t2, wl2, y2, dy2 = (p["two_" + k] for k in ("t", "wavelength", "y", "dy"))
+    mb2 = L.LombScargleMultiband(t2, y2, wl2, dy2)
+    f2 = mb2.autofrequency(nyquist_factor=5)
+    p2 = mb2.power(f2, method="fast")
+    pk2, _ = find_peaks(p2, distance=5)
+    pk2 = pk2[np.argsort(p2[pk2])][::-1][:8]
+    assert [round(float(v), 6) for v in f2[pk2]] == [round(float(v), 6) for v in p["nbmb2_peak_freqs"]]
 
 
 def test_dense_backend_vs_oracle(dev):
@@ -1852,7 +1926,9 @@ def test_host_visible_status_belongs_to_one_evaluation(dev):
 
 def test_multiband_lomb_scargle_vs_oracle(dev):
     """The multiband periodogram the reference's 2-D seeding asks for (``LombScargleMultiband(...).power(f, method='fast')``,
-    ``pgmuvi/multiband_ls_significance.py:51-106``): per-band powers by the HIP kernel, chi^2-weighted; config 4's 8 bands."""
+    ``pgmuvi/multiband_ls_significance.py:51-106``): per-band powers by the HIP kernel, combined with astropy's weights (each
+    band's summed squared power; pinned by the notebook's recorded cell, ``test_lomb_scargle_notebook_recorded_peaks``); config 4's
+    8 bands."""
     from oracle import ls_oracle as lso
     from pgmuvi_amd import lombscargle as L
     X, Y, E = syn.cfg4(n_per_band=120)

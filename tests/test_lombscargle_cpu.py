@@ -96,8 +96,8 @@ def test_batched_seeding_finds_the_injected_periods():
 
 def test_multiband_fast_periodogram_vs_oracle():
     """``LombScargleMultiband(...).power(f, method='fast')`` as ``pgmuvi/multiband_ls_significance.py`` uses it: per-band powers
-    (here through the oracle stand-in of the HIP kernel) combined with the chi^2 weights; a common period in every band
-    is the highest peak."""
+    (here through the oracle stand-in of the HIP kernel) combined with astropy's weights (each band's summed squared power:
+    ``oracle/ls_oracle.py::multiband_fast``); a common period in every band is the highest peak."""
     rng = np.random.default_rng(3)
     period = 37.0
     ts, ys, bs, es = [], [], [], []

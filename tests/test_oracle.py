@@ -144,6 +144,53 @@ def test_oracle_reproduces_committed_expectations(golden_dir, name):
     assert k >= 1
 
 
+@pytest.mark.parametrize("d,Q,n,order", [(1, 4, 300, 0), (2, 3, 257, 0), (2, 3, 257, 1)])
+def test_row_blocked_closed_form_is_the_dense_closed_form(d, Q, n, order):
+    """``mll_value_grad_closed_form_blocked`` (the form the N=8192, d=2 fixture of config 4 is made with) against the dense one."""
+    g = torch.Generator().manual_seed(n + order)
+    x = torch.rand(n, d, generator=g, dtype=D) * 100
+    y = torch.randn(n, generator=g, dtype=D)
+    noise = 0.01 + 0.05 * torch.rand(n, generator=g, dtype=D)
+    w = torch.rand(Q, generator=g, dtype=D) + 0.1
+    mu = torch.rand(Q, d, generator=g, dtype=D) * 0.1
+    v = torch.rand(Q, d, generator=g, dtype=D) * 0.02
+    a, ga = orc.mll_value_grad_closed_form(x, y, 0.1, noise, w, mu, v, order)
+    b, gb = orc.mll_value_grad_closed_form_blocked(x, y, 0.1, noise, w, mu, v, order, rows=64)
+    assert float(a) == float(b)
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-10 * float(ga[k].abs().max()), k
+
+
+def test_full_size_fixtures_of_configs_3_and_4(golden_dir):
+    """The BASELINE-size fixtures (``make_golden.py --fullsize``): config 4's 8192 inputs are the generator's, bit for bit;
+    config 3's 512 x 2048 inputs hash to the SHA-256 taken from the reference helpers' arrays; the oracle reproduces
+    the stored values of a few members (the whole set is a quarter of an hour of oracle time -- made once, in the build
+    container); the stored gradients of config 4 agree with central differences of the oracle's plain value."""
+    import hashlib
+    g = _load(golden_dir, "inputs_cfg4_n8192.npz")
+    x, y, e = syn.cfg4()
+    assert x.shape == (8192, 2) and np.array_equal(x.numpy(), g["x"]) and np.array_equal(y.numpy(), g["y"]) and np.array_equal(e.numpy(), g["yerr"])
+    for order in (0, 1):
+        exp = _load(golden_dir, f"expect_cfg4_n8192_order{order}.npz")
+        fd, an = exp["fd_check"]
+        assert abs(fd - an) < 1e-6 * max(1.0, abs(an)) and np.isfinite(exp["mll_0"])
+        assert exp["g_noise_0"].shape == (8192,) and exp["g_mu_0"].shape == (3, 2)
+    exp = _load(golden_dir, "expect_cfg3_b512_n2048.npz")
+    assert exp["mll"].shape == (512,) and np.isfinite(exp["mll"]).all()
+    sha = hashlib.sha256()
+    for i in range(512):
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=2048)
+        assert per == float(exp["lead_period"][i])
+        for a in (t, y, e):
+            sha.update(np.ascontiguousarray(a.numpy()).tobytes())
+    assert sha.digest() == exp["inputs_sha256"].tobytes()
+    for i in (0, 300, 511):
+        (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=2048)
+        h = syn.cfg_hypers(3, y.double(), lead_period=per)
+        val = orc.mll(t.double(), y.double(), h["mean"], e.double() ** 2, h["w"], h["mu"].reshape(4, 1), h["v"].reshape(4, 1))
+        assert abs(float(val) - float(exp["mll"][i])) < 1e-11
+
+
 def test_constraint_transforms_roundtrip():
     raw = torch.linspace(-5, 5, 11, dtype=D)
     assert torch.allclose(orc.inv_softplus(orc.softplus(raw)), raw, atol=1e-12)
