@@ -297,6 +297,15 @@ int pgm_factorisation_status_of(pgm_ws* ws, int64_t evaluation, int* info_host, 
  * dimensions leaf l sees (its active_dims).  theta: [batch][nparam] device values; g_theta: d mll / d theta, same shape.
  * Everything else (noise, mean, jitter, mll, info, workspace) as in pgm_mll_value_grad_batched_f64.  The workspace must
  * have been created with max_q >= nparam.
+ *
+ * PARITY STATUS OF THE LEAF FORMULAS: UNPINNED.  They are GPyTorch's published forms as restated in
+ * oracle/sm_mll_oracle.py (rbf, matern, periodic, rq, cosine) -- RBF exp(-r^2 / 2 l^2); Matern nu with r / l;
+ * periodic exp(-2 sin^2(pi r / p) / lambda) with lambda = GPyTorch's `lengthscale` entering UNSQUARED; rational
+ * quadratic (1 + r^2 / (2 alpha l^2))^-alpha; cosine cos(pi r / p).  The reference holds no recorded number that
+ * exercises any of them (its tests check shapes and symmetry only, tests/test_kernels.py; no notebook fits these
+ * models), gpytorch is not installed in the build container, so the HIP path equals the restatement to 1e-9 and the
+ * restatement is checked against nothing: the periodic kernel's lengthscale convention in particular is a reading of
+ * GPyTorch's documentation, not a verified fact.  The spectral-mixture path above is the pinned one.
  */
 typedef struct pgm_kernel_program {
   int nleaf, nterm, nparam;

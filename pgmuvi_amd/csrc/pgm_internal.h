@@ -129,6 +129,7 @@ struct pgm_ws {
   std::vector<int> rag_nb, rag_z0;   // the current trimmed set's classes: block rows, first member (+ one past the last), longest first
   int ragged_trim;       // ragged batches: the launch sets of the panel sweep are merged, nothing padded beyond a light curve's own block rows (PgmDev::trim)
   int prebuild;          // short light curves: per-point factors and kernel matrix in one launch (k_prebuild)
+  int small;             // light curves of at most 128 points (1-D spectral mixture): the whole evaluation in ONE launch (k_small; PGM_SMALL=0: the launch sequence of every other size)
   int trsm16;            // fused sweep: the chain's row solve by k_trsm16 (16 wavefronts, one memory round trip)
   int trsm64;            // fused sweep, a handful of light curves: the row solve by k_trsm64 (128 x 64 slabs, 6 look-ahead workgroups per light curve)
   int upd_big_min;       // k_update: 128x128 tiles from this many tiles x light curves on

@@ -568,9 +568,16 @@ __device__ __forceinline__ void diag_store_v(const DiagCtx& c, int s, int j, con
   }
 }
 
+// Where the diagonal block's sub-blocks come from: the matrix in memory (k_diag), or straight from the per-point factors of a
+// short light curve staged in LDS (k_small, below: the block is never written to memory).
+struct LoadFromMatrix {
+  __device__ __forceinline__ v4d operator()(const DiagCtx& c, int i, int j, int lane) const { return diag_load_block(c, i, j, lane); }
+};
+
 // a worker wavefront: its sub-blocks through all steps.  (The slot table stays packed in one scalar register pair and is
 // decoded where it is used: two dozen wave-uniform integers kept live across the loop made the compiler spill scalars.)
-__device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, int nse) {
+template <class Load = LoadFromMatrix>
+__device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, int nse, const Load load = Load()) {
   constexpr int NS = NB / DB;
   const unsigned long long pack = *reinterpret_cast<const unsigned long long*>(DIAG_OWN[q]);
 #define SLOT_E(t) ((int)((pack >> (8 * (t))) & 0xffull))
@@ -578,7 +585,7 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
 #pragma unroll
   for (int t = 0; t < DIAG_SLOTS; ++t) {
     const int e = SLOT_E(t), i = e >> 4, j = e & 15;
-    if (e != 0xff && i <= j) acc[t] = diag_load_block(c, i, j, lane);
+    if (e != 0xff && i <= j) acc[t] = load(c, i, j, lane);
     else acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   }
   for (int s = 0; s < nse; ++s) {
@@ -627,7 +634,8 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
 }
 
 // the chain wavefront
-__device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse) {
+template <class Load = LoadFromMatrix>
+__device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse, const Load load = Load()) {
 #ifdef PGM_DIAG_STAMPS
   long long st_[40]; int sn_ = 0;
 #define STAMP() do { if (sn_ < 40) st_[sn_++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -636,9 +644,9 @@ __device__ __forceinline__ void diag_chain(const DiagCtx& c, int lane, int nse) 
 #endif
   STAMP();
   __builtin_amdgcn_s_setprio(3);
-  v4d d = diag_load_block(c, 0, 0, lane);
-  v4d x = diag_load_block(c, 0, 1, lane);                     // what step 0 needs beyond (0, 0) comes straight from memory
-  v4d dn = diag_load_block(c, 1, 1, lane);
+  v4d d = load(c, 0, 0, lane);
+  v4d x = load(c, 0, 1, lane);                                // what step 0 needs beyond (0, 0) comes straight from memory
+  v4d dn = load(c, 1, 1, lane);
   // pass s: the first barrier of step s, the chain's own solve and update, then the factorisation of sub-block s+1 (the
   // factorisation is a long piece of straight-line code: ONE copy of it, pass -1 is sub-block 0 -- the workgroup's
   // neighbour CU shares the instruction cache with it and runs filler tiles)
@@ -2558,19 +2566,24 @@ __global__ __launch_bounds__(256) void k_fit_pre(FitDev F) {
   }
 }
 
-// after the evaluation: loss, gradients w.r.t. the raw parameters, optimiser step, log.  One workgroup.
-__global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __restrict__ mll, const double* __restrict__ g_w,
-                                                  const double* __restrict__ g_mu, const double* __restrict__ g_v,
-                                                  const double* __restrict__ g_noise, const double* __restrict__ g_mean) {
-  __shared__ double red[256], sums[PGM_MAX_D + 2];
+// after the evaluation: loss, gradients w.r.t. the raw parameters, optimiser step, log.  One workgroup of NT >= 256 threads, of
+// which the first 256 work (k_fit_post: NT = 256; k_small, the one-launch evaluation of a short light curve: 1024) -- the same
+// sums in the same order either way.  The evaluation's results may live in memory or in LDS (generic pointers).
+template <int NT>
+__device__ __forceinline__ void fit_post_body(const FitDev& F, const double* mll, const double* g_w, const double* g_mu, const double* g_v,
+                                              const double* g_noise, const double* g_mean, double* red /*[256]*/, double* sums /*[PGM_MAX_D + 2]*/) {
+  static_assert(NT >= 256, "the first 256 threads do the work");
   const int t = threadIdx.x;
+  const bool act = t < 256;
   // sums of dmll/dmean_i (times x_i,dd for the weights of a linear mean) and, last, of dmll/dnoise_i
   for (int which = 0; which <= F.nmean; ++which) {
     double s = 0.0;
-    if (which == F.nmean) { if (F.has_noise) for (int i = t; i < F.n; i += 256) s += g_noise[i]; }
-    else if (which == F.nmean - 1) { for (int i = t; i < F.n; i += 256) s += g_mean[i]; }
-    else { for (int i = t; i < F.n; i += 256) s += g_mean[i] * F.x[(int64_t)i * F.d + which]; }
-    red[t] = s;
+    if (act) {
+      if (which == F.nmean) { if (F.has_noise) for (int i = t; i < F.n; i += 256) s += g_noise[i]; }
+      else if (which == F.nmean - 1) { for (int i = t; i < F.n; i += 256) s += g_mean[i]; }
+      else { for (int i = t; i < F.n; i += 256) s += g_mean[i] * F.x[(int64_t)i * F.d + which]; }
+      red[t] = s;
+    }
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
     if (t == 0) sums[which] = red[0];
@@ -2592,7 +2605,7 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
       dlp = -(1.0 + zz / sg) / th;
     }
   }
-  red[t] = lp;
+  if (act) red[t] = lp;
   __syncthreads();
   for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
   const double lp_sum = red[0];
@@ -2633,6 +2646,357 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
   if (t == 0 && it < F.max_iter) F.loss_hist[it] = -(mll[0] + lp_sum / (double)F.n);
   __syncthreads();
   if (t == 0) F.it[0] = it + 1;
+}
+
+__global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __restrict__ mll, const double* __restrict__ g_w,
+                                                  const double* __restrict__ g_mu, const double* __restrict__ g_v,
+                                                  const double* __restrict__ g_noise, const double* __restrict__ g_mean) {
+  __shared__ double red[256], sums[PGM_MAX_D + 2];
+  fit_post_body<256>(F, mll, g_w, g_mu, g_v, g_noise, g_mean, red, sums);
+}
+
+// ---------------------------------------------------------------------------
+// ONE LAUNCH for a light curve of at most 128 points (round 6; 1-D spectral mixture).  The reference's one published workload is
+// N = 89 (/root/reference/paper/paper.md:113): a single diagonal block, for which an evaluation used to be k_prebuild -> k_diag ->
+// k_lauum_grad -> k_finalize -- four dependent launches of which only the second does more than a few microseconds of work -- and a
+// training iteration seven (k_fit_pre, k_precompute, k_build, k_diag, k_lauum_grad, k_finalize, k_fit_post).  Here one workgroup of
+// 16 wavefronts per light curve does all of it, and nothing but results and the state prediction reads later touches memory:
+//   A  (FIT) raw -> constrained parameters; the mixture's parameters to LDS
+//   B  per-point factors cos / sin(2 pi x mu_q), x v_q pi sqrt 2, residual and diagonal addend: LDS (and the workspace, for prediction)
+//   C  the diagonal block's factorisation exactly as k_diag runs it (diag_chain / diag_worker / the bookkeeping wavefront) -- but a
+//      wavefront BUILDS the 16x16 sub-blocks it owns straight from the factors in LDS, in the MFMA C layout they are factored in:
+//      the kernel matrix is never written to memory (same expressions as build_part_1d, hence the same matrix bits)
+//   D  V = U^-T back from the inverse image just written (L2) into LDS as 16x16 fragments; A^-1 = V^T V sub-block by sub-block over
+//      the upper triangle (4 MFMAs per sub-block row), the sub-blocks dealt to the 16 wavefronts
+//   E  G = alpha alpha^T - A^-1 contracted with dK/d(w, mu, v) in registers (the 1-D epilogue of lauum_grad_item), diag(A^-1) -> noise gradient
+//   F  mll, gradients, status -> the caller's arrays and the workspace;  (FIT) the optimiser step of k_fit_post
+// The batch rides on gridDim.z (any number of short light curves per call, each with its own length: pts()).
+// ---------------------------------------------------------------------------
+struct LoadFromFactors {
+  const double* fac;    // LDS [(3 q + k) * NB + m]: cos, sin, x v pi sqrt2 per mixture; then raw x
+  const double* wl;     // LDS [Q] mixture weights
+  const double* dadd;   // LDS [NB] diagonal addend
+  int Q, n;
+  __device__ __forceinline__ v4d operator()(const DiagCtx&, int i, int j, int lane) const {
+    const int g = lane >> 4, col = j * DB + (lane & 15);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < Q; ++q) {
+      const double wq = wl[q];
+      const double* cq = fac + q * 3 * NB;
+      const double cc0 = wq * cq[col], cs0 = wq * cq[NB + col], cv0 = cq[2 * NB + col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = i * DB + g + 4 * r;
+        const double rc = cq[m], rs = cq[NB + m], rv = cq[2 * NB + m];
+        const double d0 = rv - cv0;
+        acc[r] = __builtin_fma(exp_neg_fast(-(d0 * d0)), __builtin_fma(rc, cc0, rs * cs0), acc[r]);
+      }
+    }
+    v4d out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = i * DB + g + 4 * r;
+      double val = acc[r];
+      if (gi < n && col < n) { if (gi == col) val += dadd[gi]; }
+      else val = (gi == col) ? 1.0 : 0.0;
+      out[r] = val;
+    }
+    return out;
+  }
+};
+
+constexpr int SMALL_MAXT = 3;                                  // sub-blocks of the upper triangle per wavefront: ceil(36 / 16)
+constexpr int SMALL_VIMG = (NB / DB) * (NB / DB + 1) / 2 * DB * DB;   // 36 sub-blocks of 256
+// doubles of dynamic LDS
+__host__ __device__ constexpr int small_lds_doubles(int q) {
+  return SMALL_VIMG + (3 * q + 1) * NB + DB * DB + 8 * NB + 64 + 64 + 3 * PGM_MAX_QD + 64 + 8 + 16 * (3 * PGM_MAX_QD + 1) + 256 + 8;
+}
+
+template <bool FIT>
+__global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int NS = NB / DB;
+  const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int Q = P.q, nslot = 3 * Q + 1;
+  double* M = sm;                                   // factorisation: prow [2][8][256] | dg [8][256] | sup [8][256]; then the V image [36][256]
+  double* fac = M + SMALL_VIMG;                     // [(3 Q + 1)][NB]
+  double* uiS = fac + (3 * Q + 1) * NB;             // [256]
+  double* rsv = uiS + DB * DB;                      // residual (consumed by the forward substitution)
+  double* zsv = rsv + NB;                           // z = V r
+  double* alv = zsv + NB;                           // alpha = A^-1 r
+  double* udg = alv + NB;                           // sqrt of the pivots
+  double* dadd = udg + NB;                          // diagonal addend
+  double* dvec = dadd + NB;                         // diag(A^-1)
+  double* gme = dvec + NB;                          // dmll/dmean
+  double* gno = gme + NB;                           // dmll/dnoise
+  double* dump = gno + NB;                          // [64]
+  double* thl = dump + 64;                          // [64] (FIT) constrained parameters
+  double* hypl = thl + 64;                          // [3 * PGM_MAX_QD] w | mu | v
+  double* outs = hypl + 3 * PGM_MAX_QD;             // [64] mll, g_w, g_mu, g_v
+  double* misc = outs + 64;                         // [8] 0: log det, 1: status
+  double* wpart = misc + 8;                         // [16][nslot]
+  double* red = wpart + 16 * (3 * PGM_MAX_QD + 1);  // [256] (FIT)
+  double* sums = red + 256;                         // [8]   (FIT)
+  const int cb = caller_slot(P, b), n = pts(P, b);
+  const int nse = __builtin_amdgcn_readfirstlane((n + DB - 1) / DB);
+  double* pre = P.pre + b * P.sPre;
+
+  // ---- A: the mixture's parameters
+  if (FIT) {
+    if (t < F.P) { const double th = fit_theta(F, t); thl[t] = th; F.theta[t] = th; if (F.has_noise && t == F.P - 1) F.noise_scalar[0] = th; }
+    __syncthreads();
+  }
+  if (t < 3 * Q) {
+    double val;
+    if (FIT) val = thl[F.nmean + t];
+    else if (t < Q) val = P.w[(int64_t)cb * Q + t];
+    else if (t < 2 * Q) val = P.mu[(int64_t)cb * Q + (t - Q)];
+    else val = P.v[(int64_t)cb * Q + (t - 2 * Q)];
+    hypl[t] = val;
+    P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = val;
+  }
+  __syncthreads();
+  // ---- B: per-point factors
+  const double nscal = FIT ? (F.has_noise ? thl[F.P - 1] : 0.0)
+                           : P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0);
+  for (int e = t; e < NB * Q; e += DIAG_THREADS) {
+    const int m = e & (NB - 1), q = e >> 7;
+    const int64_t ci = (int64_t)cb * P.cstride + m;
+    const double xi = (m < n) ? P.x[ci] : 0.0;
+    const double mu = hypl[Q + q], v = hypl[2 * Q + q];
+    double sn, cs;
+    sincospi(2.0 * (xi * mu), &sn, &cs);
+    const double xv = xi * v * PI_SQRT2;
+    fac[(q * 3 + 0) * NB + m] = cs; fac[(q * 3 + 1) * NB + m] = sn; fac[(q * 3 + 2) * NB + m] = xv;
+    pre[(int64_t)(q * 3 + 0) * P.np + m] = cs; pre[(int64_t)(q * 3 + 1) * P.np + m] = sn; pre[(int64_t)(q * 3 + 2) * P.np + m] = xv;
+  }
+  if (t < NB) {
+    const int m = t;
+    const bool valid = m < n;
+    const int64_t ci = (int64_t)cb * P.cstride + m;
+    const double xi = valid ? P.x[ci] : 0.0;
+    fac[3 * Q * NB + m] = xi;
+    pre[(int64_t)(3 * Q) * P.np + m] = xi;
+    double mean_i;
+    if (FIT) {
+      mean_i = thl[F.nmean - 1];                               // the constant, or the bias of a linear mean (d = 1: one weight)
+      if (F.nmean > 1) mean_i += xi * thl[0];
+      if (valid) F.mean_vec[m] = mean_i;
+    } else mean_i = valid ? P.mean[ci] : 0.0;
+    const double rr = valid ? (P.y[ci] - mean_i) : 0.0;
+    const double da = valid ? ((P.noise ? P.noise[ci] : 0.0) + nscal + P.jitter) : 0.0;
+    rsv[m] = rr; zsv[m] = 0.0; alv[m] = 0.0; dadd[m] = da; dvec[m] = 0.0;
+    const int64_t vi = (int64_t)b * P.sVec + m;
+    P.r[vi] = rr; P.diagadd[vi] = da;
+  }
+  if (t == 0) { misc[0] = 0.0; misc[1] = 0.0; }
+  __syncthreads();
+
+  // ---- C: the factorisation (the roles of k_diag's workgroup 0)
+  DiagCtx c;
+  c.prow = M; c.dg = M + 2 * NS * DB * DB; c.sup = c.dg + NS * DB * DB;
+  c.uiS = uiS; c.udg = udg; c.dump = dump;
+  c.Akk = nullptr; c.ld = 0;
+  c.Dinv0 = P.Dinv + b * P.sDinv;
+  c.Dinv1 = c.Dinv0 + NB * NB;
+  const LoadFromFactors load{fac, hypl, dadd, Q, n};
+  if (wave == 0) {
+    diag_chain(c, lane, nse, load);
+  } else if ((wave & 3) != 0) {
+    diag_worker(c, wave - 1 - (wave >> 2), lane, nse, load);
+  } else if (wave == 4) {
+    double lgsum = 0.0;
+    int firstbad = -1;
+    for (int s = 0; s < nse; ++s) {
+      const double* row = c.prow + (s & 1) * NS * DB * DB;
+      lds_barrier();
+      if (lane < DB) {                                           // z_s = V_ss r_s (r_s is final since step s-1)
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < DB; ++kk) acc += uiS[kk * DB + lane] * rsv[s * DB + kk];
+        zsv[s * DB + lane] = acc;
+      }
+      lds_barrier();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int colg = lane + 64 * u, jb = colg / DB;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < DB; ++m) acc += row[jb * DB * DB + m * DB + (colg - jb * DB)] * zsv[s * DB + m];
+        if (jb > s) rsv[colg] -= acc; else alv[colg] += acc;
+      }
+      {
+        const double u = udg[s * DB + (lane & 15)];
+        const unsigned long long badm = __ballot(!(u > 0.0 && u < 1e300)) & 0xffffull;
+        if (badm && firstbad < 0) firstbad = s * DB + (int)__builtin_ctzll(badm);
+        if (lane < DB) lgsum += 2.0 * log(u);
+      }
+    }
+    const double tot = wave_sum(lgsum);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      P.z[b * P.sVec + lane + 64 * u] = zsv[lane + 64 * u];
+      P.alpha[b * P.sVec + lane + 64 * u] = alv[lane + 64 * u];
+    }
+    if (lane == 0) {
+      P.logdet[b * P.sLogdet] = tot;
+      misc[0] = tot;
+      misc[1] = firstbad >= 0 ? (double)(1 + firstbad) : 0.0;
+    }
+  } else {
+    // waves 8 and 12: V_ss leaves for the two inverse images (one each)
+    const int kq = lane >> 4, nn = lane & 15;
+    for (int s = 0; s < NS; ++s) {
+      v4d v;
+      if (s < nse) {
+        lds_barrier();
+        v = diag_get(c.prow + (s & 1) * NS * DB * DB + s * DB * DB, lane);
+        lds_barrier();
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (kq + 4 * r == nn) ? 1.0 : 0.0;
+      }
+      diag_store_v(c, s, s, v, lane, wave == 8 ? 1 : 2);
+    }
+  }
+  __syncthreads();                                              // (every store of the inverse images has drained: vmcnt(0) in front of the barrier)
+  const int bad = (int)misc[1];
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  const double half_n = 0.5 / (double)n;
+
+  if (P.need_grad && !bad) {
+    // ---- D: V -> LDS as sub-block fragments; block (s, j), j <= s, at s (s + 1) / 2 + j, row-major 16 x 16
+    const int T = nse * (nse + 1) / 2;
+    for (int e = t; e < T * DB * DB; e += DIAG_THREADS) {
+      const int blk = e >> 8, w = e & 255;
+      int jj, ss;
+      tri_decode(blk, jj, ss);
+      M[e] = c.Dinv1[(ss * DB + (w >> 4)) * NB + jj * DB + (w & 15)];
+    }
+    for (int e = t; e < 16 * nslot; e += DIAG_THREADS) wpart[e] = 0.0;
+    __syncthreads();
+    // A^-1 sub-block (i, j), i <= j:  sum over s >= j of V(s, i)^T V(s, j)
+    v4d G[SMALL_MAXT];
+    int ti[SMALL_MAXT], tj[SMALL_MAXT];
+    int nt = 0;
+#pragma unroll
+    for (int k = 0; k < SMALL_MAXT; ++k) {
+      const int u = wave + 16 * k;
+      G[k] = v4d{0.0, 0.0, 0.0, 0.0};
+      ti[k] = 0; tj[k] = 0;
+      if (u < T) {
+        int i, j;
+        tri_decode(u, i, j);
+        i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
+        ti[k] = i; tj[k] = j; nt = k + 1;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int s2 = j; s2 < nse; ++s2) {
+          const double* pa = M + (s2 * (s2 + 1) / 2 + i) * DB * DB + lane;
+          const double* pb = M + (s2 * (s2 + 1) / 2 + j) * DB * DB + lane;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[64 * r], pb[64 * r], acc, 0, 0, 0);
+        }
+        // G = weight * (alpha alpha^T - A^-1) on the valid pairs; the diagonal of A^-1 for the noise gradient
+        const int g = lane >> 4, col = j * DB + (lane & 15);
+        const double wt = (i == j) ? 1.0 : 2.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = i * DB + g + 4 * r;
+          if (i == j && m == col) dvec[m] = acc[r];
+          G[k][r] = (m < n && col < n) ? wt * (alv[m] * alv[col] - acc[r]) : 0.0;
+        }
+      }
+    }
+    // ---- E: the contraction with dK/d(w, mu, v) (the 1-D epilogue of lauum_grad_item on 16 x 16 sub-blocks)
+    const double* xs = fac + 3 * Q * NB;
+    double* mypart = wpart + wave * nslot;
+#pragma unroll 1
+    for (int q = 0; q < Q; ++q) {
+      const double* rq = fac + q * 3 * NB;
+      double gw = 0.0, gmu = 0.0, gv = 0.0;
+#pragma unroll
+      for (int k = 0; k < SMALL_MAXT; ++k) {
+        if (k >= nt) continue;
+        const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
+        const double cc_ = rq[col], cs_ = rq[NB + col], cv = rq[2 * NB + col], cx = xs[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = ti[k] * DB + g + 4 * r;
+          const double rc = rq[m], rs = rq[NB + m], rv = rq[2 * NB + m], rx = xs[m];
+          const double ds = rv - cv;
+          const double GE = G[k][r] * exp_neg_fast(-(ds * ds));
+          const double CC = __builtin_fma(rc, cc_, rs * cs_);
+          const double SN = __builtin_fma(rs, cc_, -(rc * cs_));
+          const double tau = rx - cx;
+          const double tt = GE * tau;
+          gw = __builtin_fma(GE, CC, gw);
+          gmu = __builtin_fma(tt, SN, gmu);
+          gv = __builtin_fma(tt, CC * tau, gv);
+        }
+      }
+      gw = wave_sum(gw); gmu = wave_sum(gmu); gv = wave_sum(gv);
+      if (lane == 0) { mypart[q] = gw; mypart[Q + q] = gmu; mypart[2 * Q + q] = gv; }
+    }
+    __syncthreads();
+  }
+
+  // ---- F: results.  (A failed factorisation leaves NaN in every output, as k_finalize does.)
+  if (wave == 0) {
+    // (the order of k_finalize's sums, so that a light curve has the same value bit for bit whichever path evaluates it -- alone
+    //  here, or as a member of a ragged launch set through the launch sequence: thread i holds z_i^2, thread 0 also the log det,
+    //  one wavefront sum per 64 points, the two added in order)
+    double s_lo = zsv[lane] * zsv[lane], s_hi = zsv[lane + 64] * zsv[lane + 64];
+    if (lane == 0) s_lo += misc[0];
+    s_lo = wave_sum(s_lo); s_hi = wave_sum(s_hi);
+    if (lane == 0) {
+      double tot = 0.0;
+      tot += s_lo; tot += s_hi;
+      const double val = bad ? qnan : -0.5 * (tot + (double)n * log(2.0 * PI)) / (double)n;
+      outs[0] = val;
+      P.out_small[b * P.sOut] = val;
+      if (P.mll) P.mll[cb] = val;
+      P.info[b] = bad;
+      if (P.info_out) P.info_out[cb] = bad;
+      if (P.info_host) {
+        P.info_host[b] = bad;
+        __threadfence_system();
+        P.seq_host[b] = P.seq;
+      }
+    }
+  }
+  if (P.need_grad) {
+    if (t >= 64 && t < 64 + 3 * Q) {                            // slot s of the hyper-parameter gradients: w (Q), mu (Q), v (Q)
+      const int s3 = t - 64;
+      double acc = 0.0;
+      for (int wv = 0; wv < 16; ++wv) acc += wpart[wv * nslot + s3];     // fixed order
+      double val;
+      if (s3 < Q) val = half_n * acc;
+      else if (s3 < 2 * Q) val = half_n * (-2.0 * PI) * hypl[s3 - Q] * acc;
+      else val = half_n * (-2.0 * TWO_PI_SQ) * hypl[s3] * hypl[s3 - 2 * Q] * acc;
+      if (bad) val = qnan;
+      outs[1 + s3] = val;
+      P.out_small[b * P.sOut + 1 + s3] = val;
+      if (s3 < Q) { if (P.g_w) P.g_w[(int64_t)cb * Q + s3] = val; }
+      else if (s3 < 2 * Q) { if (P.g_mu) P.g_mu[(int64_t)cb * Q + (s3 - Q)] = val; }
+      else { if (P.g_v) P.g_v[(int64_t)cb * Q + (s3 - 2 * Q)] = val; }
+    }
+    if (t >= 128 && t < 128 + NB) {
+      const int m = t - 128;
+      const double al = alv[m];
+      const double gm = bad ? qnan : al / (double)n, gn = bad ? qnan : half_n * (al * al - dvec[m]);
+      gme[m] = (m < n) ? gm : 0.0; gno[m] = (m < n) ? gn : 0.0;
+      if (m < n) {
+        P.out_gmean[b * P.sVec + m] = gm; P.out_gnoise[b * P.sVec + m] = gn;
+        if (P.g_mean) P.g_mean[(int64_t)cb * P.cstride + m] = gm;
+        if (P.g_noise) P.g_noise[(int64_t)cb * P.cstride + m] = gn;
+      }
+    }
+  }
+  if (FIT) {
+    __syncthreads();
+    fit_post_body<DIAG_THREADS>(F, outs, outs + 1, outs + 1 + Q, outs + 1 + 2 * Q, gno, gme, red, sums);
+  }
 }
 
 // ---------------------------------------------------------------------------

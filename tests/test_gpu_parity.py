@@ -1672,6 +1672,71 @@ def test_row_solve_of_small_batches_is_bit_for_bit_the_slab_kernels(dev, monkeyp
             assert _rel(outs["1"][f"g_{p}"].reshape(batch, -1)[0], gr[p].reshape(-1)) < GRAD_RTOL, p
 
 
+@pytest.mark.parametrize("n,q,batch", [(1, 1, 1), (2, 2, 1), (17, 2, 1), (89, 2, 1), (127, 4, 1), (128, 4, 1), (100, 16, 1), (96, 3, 5), (128, 4, 37)])
+def test_one_launch_for_at_most_128_points(dev, monkeypatch, n, q, batch):
+    """Light curves of at most 128 points (the reference's one published workload is N = 89, ``/root/reference/paper/paper.md:113``)
+    take ONE launch, k_small -- factors, the matrix's sub-blocks built in the registers they are factored in, the inverse, the
+    gradient contraction and the results -- where every other size takes the launch sequence (PGM_SMALL=0 gives that sequence
+    here too).  Same factor, so the value, z and alpha agree to the last bits; the gradient sums are split over 16 x 16
+    sub-blocks instead of quarter tiles: 1e-12.  Both against the oracle (1e-9 / 1e-7); value-only; every mixture count up to
+    16; batches (one workgroup per light curve); a matrix that is not positive definite is reported the same way."""
+    gen = torch.Generator().manual_seed(1000 * n + q + batch)
+    X = torch.sort(torch.rand(batch, n, generator=gen, dtype=D) * 400, dim=1)[0]
+    Y = torch.randn(batch, n, generator=gen, dtype=D)
+    Z = 0.01 + 0.05 * torch.rand(batch, n, generator=gen, dtype=D)
+    W = 0.1 + torch.rand(batch, q, generator=gen, dtype=D)
+    MU = 0.005 + 0.2 * torch.rand(batch, q, 1, generator=gen, dtype=D)
+    V = 0.002 + 0.02 * torch.rand(batch, q, 1, generator=gen, dtype=D)
+    ME = 0.3 * torch.randn(batch, 1, generator=gen, dtype=D).expand(batch, n).contiguous()
+    args = lambda: (X.unsqueeze(-1).to(dev), Y.to(dev), ME.to(dev), Z.to(dev), None, W.to(dev), MU.to(dev), V.to(dev), 0, 0.0)
+    outs = {}
+    for sw in ("1", "0"):
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_SMALL", sw)
+        o = _hip.mll_value_grad(*args(), True)
+        o0 = _hip.mll_value_grad(*args(), False)
+        torch.cuda.synchronize()
+        outs[sw] = {k: t.clone().cpu() for k, t in o.items() if torch.is_tensor(t)}
+        assert torch.equal(o0["mll"].cpu(), outs[sw]["mll"])       # value-only: the same arithmetic
+    monkeypatch.delenv("PGM_SMALL")
+    _hip.release_workspaces()
+    a, b_ = outs["1"], outs["0"]
+    assert int(a["info"].abs().sum()) == 0 and int(b_["info"].abs().sum()) == 0
+    assert float((a["mll"] - b_["mll"]).abs().max()) < 1e-13
+    for key in ("g_w", "g_mu", "g_v", "g_noise", "g_mean"):
+        assert _rel(a[key].reshape(-1), b_[key].reshape(-1)) < 1e-12, key
+    for i in sorted({0, batch - 1}):
+        val, gr = orc.mll_value_grad_closed_form(X[i], Y[i], ME[i], Z[i], W[i], MU[i], V[i])
+        assert abs(float(a["mll"][i]) - float(val)) < MLL_TOL
+        for p_ in ("w", "mu", "v", "noise", "mean"):
+            assert _rel(a[f"g_{p_}"][i].reshape(-1), gr[p_].reshape(-1)) < GRAD_RTOL, (p_, i)
+
+
+def test_one_launch_path_reports_a_failed_factorisation_and_learned_noise(dev):
+    """k_small: a matrix that is not positive definite (repeated times, no noise, a negative jitter) -> info > 0 and NaN in every
+    output, the next evaluation on the same workspace is clean; a learned scalar noise (``noise_scalar`` per light curve, no
+    fixed noise) against the oracle."""
+    n = 60
+    gen = torch.Generator().manual_seed(5)
+    x = torch.sort(torch.rand(n, generator=gen, dtype=D) * 100)[0]
+    x[10] = x[9]
+    y = torch.randn(n, generator=gen, dtype=D)
+    w = torch.tensor([0.8], dtype=D); mu = torch.tensor([[0.05]], dtype=D); v = torch.tensor([[0.01]], dtype=D)
+    out = _hip.mll_value_grad(x.reshape(n, 1).to(dev), y.to(dev), torch.zeros(n, dtype=D, device=dev), None, None, w.to(dev), mu.to(dev), v.to(dev),
+                              0, -1e-3, True)
+    torch.cuda.synchronize()
+    assert int(out["info"]) > 0 and torch.isnan(out["mll"]).all() and torch.isnan(out["g_w"]).all() and torch.isnan(out["g_noise"]).all()
+    ns = torch.tensor(0.07, dtype=D)
+    out = _hip.mll_value_grad(x.reshape(n, 1).to(dev), y.to(dev), torch.zeros(n, dtype=D, device=dev), None, ns.to(dev), w.to(dev), mu.to(dev), v.to(dev),
+                              0, 0.0, True)
+    torch.cuda.synchronize()
+    val, gr = orc.mll_value_grad_closed_form(x, y, 0.0, ns, w, mu, v)
+    assert int(out["info"]) == 0 and abs(float(out["mll"]) - float(val)) < MLL_TOL
+    assert abs(float(out["g_noise"].sum()) - float(gr["noise"])) < GRAD_RTOL * max(1.0, abs(float(gr["noise"])))
+    for p_ in ("w", "mu", "v", "mean"):
+        assert _rel(out[f"g_{p_}"].reshape(-1), gr[p_].reshape(-1)) < GRAD_RTOL, p_
+
+
 @pytest.mark.parametrize("n", [130, 255, 383, 640, 897, 1409, 2049, 3970, 5120, 5130])
 def test_every_schedule_switch_off_gives_the_same_light_curve(dev, monkeypatch, n):
     """Awkward lengths (one point into a new block, one short of a full one, the last fused size) through the default
