@@ -92,6 +92,7 @@ struct PgmDev {
   int prebuilt;       // 1: the kernel matrix was built in front of the graph, by k_prebuild together with the per-point factors (short light curves)
   int build_beside;   // 1: k_build builds block row 0 only, the rest of the matrix is built by the spare workgroups of diagonal block 0's launch
   int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups)
+  int small_eval;     // 1: k_small evaluated this call (the inverse images' identity padding is completed on demand: k_small_pad)
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
   KProg prog;
 };

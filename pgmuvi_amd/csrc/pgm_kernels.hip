@@ -20,6 +20,24 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// The same sum without the LDS crossbar (wave_sum's __shfl_xor is ds_bpermute_b32, ~100 cycles of latency per step and two per
+// double): four DPP steps inside each row of 16 lanes -- quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- then the
+// four row totals by v_readlane.  Every lane returns the total.  A different association than wave_sum's butterfly: used where
+// sums are compared to rounding (the gradient partial sums of k_small), never where bits are (the value's sums).
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+#define PGM_DPP_STEP(CTRL) do { \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true); \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true); \
+    v += __hiloint2double(hi, lo); } while (0)
+  PGM_DPP_STEP(0xB1);
+  PGM_DPP_STEP(0x4E);
+  PGM_DPP_STEP(0x141);
+  PGM_DPP_STEP(0x140);
+#undef PGM_DPP_STEP
+  auto rl = [](double x, int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l)); };
+  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+
 // exp(x) for x <= 0 in fp64, ~1 ulp: n = rint(x log2 e), r = x - n ln 2 (two-part), degree-13 Taylor
 // polynomial on |r| <= ln2/2 (truncation 4e-18), scaled by 2^n with v_ldexp_f64 (underflows to 0
 // by itself).  19 instructions against ~35 for the library call; every N^2 pass pays one per
@@ -573,11 +591,16 @@ __device__ __forceinline__ void diag_store_v(const DiagCtx& c, int s, int j, con
 struct LoadFromMatrix {
   __device__ __forceinline__ v4d operator()(const DiagCtx& c, int i, int j, int lane) const { return diag_load_block(c, i, j, lane); }
 };
+// What a worker does with the finished block row of step s (LDS image `row`) besides its updates: nothing (k_diag), or its share of
+// the products A^-1 (i, j) += V(s, i)^T V(s, j) (k_small: the inverse accumulates while the chain factors the next sub-block).
+struct NoRowHook {
+  __device__ __forceinline__ void operator()(int, const double*, int) const {}
+};
 
 // a worker wavefront: its sub-blocks through all steps.  (The slot table stays packed in one scalar register pair and is
 // decoded where it is used: two dozen wave-uniform integers kept live across the loop made the compiler spill scalars.)
-template <class Load = LoadFromMatrix>
-__device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, int nse, const Load load = Load()) {
+template <class Load = LoadFromMatrix, class Hook = NoRowHook, bool PAD_STORES = true>
+__device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, int nse, const Load load = Load(), Hook&& hook = Hook()) {
   constexpr int NS = NB / DB;
   const unsigned long long pack = *reinterpret_cast<const unsigned long long*>(DIAG_OWN[q]);
 #define SLOT_E(t) ((int)((pack >> (8 * (t))) & 0xffull))
@@ -599,6 +622,10 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
         diag_put(row + j * DB * DB, acc[t], lane);
       }
     }
+    // (the hook's work on block row s-1 -- its image, the other parity, stays until row s+1 is published -- goes HERE: between
+    //  the two barriers of a step the workers wait for the chain, which solves, updates and factors a mini-panel before it meets
+    //  the second one; behind the updates below it would delay the next step's first barrier: k_small, +7 .. 12 % on the chain)
+    if (s > 0) hook(s - 1, c.prow + ((s - 1) & 1) * NS * DB * DB, lane);
     lds_barrier();                                             // block row s is in LDS
 #pragma unroll
     for (int t = 0; t < DIAG_SLOTS; ++t) {
@@ -624,11 +651,15 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
       if (i == s && j < s) diag_store_v(c, s, j, acc[t], lane);
     }
   }
+  if (nse > 0) hook(nse - 1, c.prow + ((nse - 1) & 1) * NS * DB * DB, lane);
   // block rows of identity padding (the last diagonal block of a light curve whose length is no multiple of 128): zero blocks
+  // (PAD_STORES false, k_small: two otherwise idle wavefronts write them, off the workers' path)
+  if constexpr (PAD_STORES) {
 #pragma unroll
-  for (int t = 0; t < DIAG_SLOTS; ++t) {
-    const int e = SLOT_E(t), i = e >> 4, j = e & 15;
-    if (i >= nse && i < NS && j < i) diag_store_v(c, i, j, acc[t], lane);
+    for (int t = 0; t < DIAG_SLOTS; ++t) {
+      const int e = SLOT_E(t), i = e >> 4, j = e & 15;
+      if (i >= nse && i < NS && j < i) diag_store_v(c, i, j, acc[t], lane);
+    }
   }
 #undef SLOT_E
 }
@@ -2527,6 +2558,7 @@ struct FitDev {
   double* m1;           // [P] Adam first moment
   double* m2;           // [P] Adam second moment
   int* it;              // [1] iterations done so far
+  int* it_host;         // host-mapped copy of it (+ [1]: the evaluation's status, written by the evaluation itself): the host reads the log without a device copy
   double* loss_hist;    // [max_iter]
   double* raw_hist;     // [max_iter][P] raw parameters after each step
   // priors on the constrained parameters (MAP): the reference's ExactMarginalLogLikelihood adds sum log p(theta) before the
@@ -2569,33 +2601,69 @@ __global__ __launch_bounds__(256) void k_fit_pre(FitDev F) {
 // after the evaluation: loss, gradients w.r.t. the raw parameters, optimiser step, log.  One workgroup of NT >= 256 threads, of
 // which the first 256 work (k_fit_post: NT = 256; k_small, the one-launch evaluation of a short light curve: 1024) -- the same
 // sums in the same order either way.  The evaluation's results may live in memory or in LDS (generic pointers).
+// What one parameter's thread reads from memory for the step: loaded where the kernel starts (k_small: the loads complete behind
+// the whole evaluation instead of in front of the step).
+struct FitLoads {
+  double raw, ca, cb, ploc, pscale, m1, m2;
+  int ckind, pkind, it;
+};
+__device__ __forceinline__ FitLoads fit_loads(const FitDev& F) {
+  FitLoads L;
+  const int t = threadIdx.x;
+  L.it = F.it[0];
+  L.raw = L.ca = L.cb = L.ploc = L.pscale = L.m1 = L.m2 = 0.0; L.ckind = L.pkind = 0;
+  if (t < F.P) {
+    L.raw = F.raw[t]; L.ckind = F.ckind[t]; L.ca = F.ca[t]; L.cb = F.cb[t];
+    L.pkind = F.pkind[t]; L.ploc = F.ploc[t]; L.pscale = F.pscale[t]; L.m1 = F.m1[t]; L.m2 = F.m2[t];
+  }
+  return L;
+}
+__device__ __forceinline__ double fit_theta_of(const FitLoads& L) {
+  if (L.ckind == 1) return softplus_d(L.raw) + L.ca;
+  if (L.ckind == 2) return L.ca - softplus_d(-L.raw);
+  if (L.ckind == 3) return sigmoid_d(L.raw) * L.cb + L.ca;
+  return L.raw;
+}
+
 template <int NT>
-__device__ __forceinline__ void fit_post_body(const FitDev& F, const double* mll, const double* g_w, const double* g_mu, const double* g_v,
+__device__ __forceinline__ void fit_post_body(const FitDev& F, const FitLoads& L, const double* mll, const double* g_w, const double* g_mu, const double* g_v,
                                               const double* g_noise, const double* g_mean, double* red /*[256]*/, double* sums /*[PGM_MAX_D + 2]*/) {
   static_assert(NT >= 256, "the first 256 threads do the work");
   const int t = threadIdx.x;
-  const bool act = t < 256;
   // sums of dmll/dmean_i (times x_i,dd for the weights of a linear mean) and, last, of dmll/dnoise_i
-  for (int which = 0; which <= F.nmean; ++which) {
-    double s = 0.0;
-    if (act) {
+  if constexpr (NT > 256) {
+    // (k_small: at most 128 points, the evaluation's results in LDS: one wavefront per sum, one barrier)
+    const int wave = t >> 6, lane = t & 63;
+    if (wave <= F.nmean) {
+      const int which = wave;
+      double s = 0.0;
+      if (which == F.nmean) { if (F.has_noise) for (int i = lane; i < F.n; i += 64) s += g_noise[i]; }
+      else if (which == F.nmean - 1) { for (int i = lane; i < F.n; i += 64) s += g_mean[i]; }
+      else { for (int i = lane; i < F.n; i += 64) s += g_mean[i] * F.x[(int64_t)i * F.d + which]; }
+      s = wave_sum_dpp(s);
+      if (lane == 0) sums[which] = s;
+    }
+    __syncthreads();
+  } else {
+    for (int which = 0; which <= F.nmean; ++which) {
+      double s = 0.0;
       if (which == F.nmean) { if (F.has_noise) for (int i = t; i < F.n; i += 256) s += g_noise[i]; }
       else if (which == F.nmean - 1) { for (int i = t; i < F.n; i += 256) s += g_mean[i]; }
       else { for (int i = t; i < F.n; i += 256) s += g_mean[i] * F.x[(int64_t)i * F.d + which]; }
       red[t] = s;
+      __syncthreads();
+      for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
+      if (t == 0) sums[which] = red[0];
+      __syncthreads();
     }
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
-    if (t == 0) sums[which] = red[0];
-    __syncthreads();
   }
-  const int it = F.it[0];
+  const int it = L.it;
   // log prior of every parameter and its derivative w.r.t. the constrained value
   double lp = 0.0, dlp = 0.0;
-  if (t < F.P && F.pkind[t] != 0) {
-    const double th = F.theta[t], mu = F.ploc[t], sg = F.pscale[t];
+  if (t < F.P && L.pkind != 0) {
+    const double th = fit_theta_of(L), mu = L.ploc, sg = L.pscale;
     constexpr double HALF_LOG_2PI = 0.91893853320467274178;
-    if (F.pkind[t] == 1) {
+    if (L.pkind == 1) {
       const double zz = (th - mu) / sg;
       lp = -0.5 * zz * zz - log(sg) - HALF_LOG_2PI;
       dlp = -zz / sg;
@@ -2605,14 +2673,19 @@ __device__ __forceinline__ void fit_post_body(const FitDev& F, const double* mll
       dlp = -(1.0 + zz / sg) / th;
     }
   }
-  if (act) red[t] = lp;
-  __syncthreads();
-  for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
-  const double lp_sum = red[0];
+  double lp_sum;
+  if constexpr (NT > 256) {
+    lp_sum = t < 64 ? wave_sum_dpp(lp) : 0.0;                  // (P <= 51 parameters: all of them in wavefront 0, and so is thread 0, the only reader)
+  } else {
+    red[t] = lp;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (t < h) red[t] += red[t + h]; __syncthreads(); }
+    lp_sum = red[0];
+  }
   // a failed factorisation (NaN value and gradients): the step is skipped -- parameters and moments stay as they are, the
   // log holds the NaN loss for the host to find at its next read
   const bool ok = isfinite(mll[0]);
-  if (t < F.P && it < F.max_iter && !ok) F.raw_hist[(int64_t)it * F.P + t] = F.raw[t];
+  if (t < F.P && it < F.max_iter && !ok) F.raw_hist[(int64_t)it * F.P + t] = L.raw;
   if (t < F.P && it < F.max_iter && ok) {
     const int p = t, o = F.nmean;
     double gth;                                             // d(-mll)/d theta_p
@@ -2622,19 +2695,19 @@ __device__ __forceinline__ void fit_post_body(const FitDev& F, const double* mll
     else if (p < o + F.q + 2 * F.qd) gth = -g_v[p - o - F.q - F.qd];
     else gth = -sums[F.nmean];
     gth -= dlp / (double)F.n;
-    const double r = F.raw[p];
+    const double r = L.raw;
     double dth = 1.0;                                       // d theta / d raw
-    if (F.ckind[p] == 1) dth = sigmoid_d(r);
-    else if (F.ckind[p] == 2) dth = sigmoid_d(-r);
-    else if (F.ckind[p] == 3) { const double sg = sigmoid_d(r); dth = F.cb[p] * sg * (1.0 - sg); }
+    if (L.ckind == 1) dth = sigmoid_d(r);
+    else if (L.ckind == 2) dth = sigmoid_d(-r);
+    else if (L.ckind == 3) { const double sg = sigmoid_d(r); dth = L.cb * sg * (1.0 - sg); }
     const double g = gth * dth;
     double x = r;
     if (F.optimizer == 0) {
       x = r - F.lr * g;
     } else {
       if (F.optimizer == 2) x = r * (1.0 - F.lr * F.weight_decay);
-      const double a = F.beta1 * F.m1[p] + (1.0 - F.beta1) * g;
-      const double v2 = F.beta2 * F.m2[p] + (1.0 - F.beta2) * g * g;
+      const double a = F.beta1 * L.m1 + (1.0 - F.beta1) * g;
+      const double v2 = F.beta2 * L.m2 + (1.0 - F.beta2) * g * g;
       F.m1[p] = a; F.m2[p] = v2;
       const double step = (double)(it + 1);
       const double bc1 = 1.0 - pow(F.beta1, step), bc2 = 1.0 - pow(F.beta2, step);
@@ -2644,15 +2717,18 @@ __device__ __forceinline__ void fit_post_body(const FitDev& F, const double* mll
     F.raw_hist[(int64_t)it * F.P + p] = x;
   }
   if (t == 0 && it < F.max_iter) F.loss_hist[it] = -(mll[0] + lp_sum / (double)F.n);
-  __syncthreads();
-  if (t == 0) F.it[0] = it + 1;
+  if (t == 0) {                                             // (every thread read the counter when the kernel started)
+    F.it[0] = it + 1;
+    if (F.it_host) { __threadfence_system(); F.it_host[0] = it + 1; }       // (behind this iteration's log entries)
+  }
 }
 
 __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __restrict__ mll, const double* __restrict__ g_w,
                                                   const double* __restrict__ g_mu, const double* __restrict__ g_v,
                                                   const double* __restrict__ g_noise, const double* __restrict__ g_mean) {
   __shared__ double red[256], sums[PGM_MAX_D + 2];
-  fit_post_body<256>(F, mll, g_w, g_mu, g_v, g_noise, g_mean, red, sums);
+  const FitLoads L = fit_loads(F);
+  fit_post_body<256>(F, L, mll, g_w, g_mu, g_v, g_noise, g_mean, red, sums);
 }
 
 // ---------------------------------------------------------------------------
@@ -2741,11 +2817,33 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   const int cb = caller_slot(P, b), n = pts(P, b);
   const int nse = __builtin_amdgcn_readfirstlane((n + DB - 1) / DB);
   double* pre = P.pre + b * P.sPre;
+#ifdef PGM_SMALL_STAMPS       // (lab build: clock ticks of the phases, wavefront 0 / a worker / the bookkeeper; printed by thread 0 of light curve 0)
+  __shared__ long long stw_[16][4];
+  long long sst_[12]; int ssn_ = 0;
+#define SSTAMP() do { if (ssn_ < 12) sst_[ssn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP() do {} while (0)
+#endif
+  SSTAMP();
+  // (The inverse images' identity padding -- rows of sub-blocks the light curve does not have -- is NOT written here: only
+  //  prediction multiplies with whole 128 x 128 images, and it completes them first, k_small_pad: up to 100 KB of stores per
+  //  evaluation of a short light curve otherwise.  No barrier of this kernel waits for memory: lds_barrier.)
 
+  // (the observation time this thread needs in phase B, requested now: its round trip overlaps that of the parameters)
+  const double x_pre = ((t & (NB - 1)) < n) ? P.x[(int64_t)cb * P.cstride + (t & (NB - 1))] : 0.0;
+  double y_pre = 0.0, nz_pre = 0.0, mean_pre = 0.0;
+  if (t < NB && t < n) {
+    const int64_t ci = (int64_t)cb * P.cstride + t;
+    y_pre = P.y[ci];
+    nz_pre = P.noise ? P.noise[ci] : 0.0;
+    if (!FIT) mean_pre = P.mean[ci];
+  }
   // ---- A: the mixture's parameters
+  FitLoads L;
   if (FIT) {
-    if (t < F.P) { const double th = fit_theta(F, t); thl[t] = th; F.theta[t] = th; if (F.has_noise && t == F.P - 1) F.noise_scalar[0] = th; }
-    __syncthreads();
+    L = fit_loads(F);                                           // (everything the optimiser step at the end reads from memory, now)
+    if (t < F.P) { const double th = fit_theta_of(L); thl[t] = th; F.theta[t] = th; if (F.has_noise && t == F.P - 1) F.noise_scalar[0] = th; }
+    lds_barrier();
   }
   if (t < 3 * Q) {
     double val;
@@ -2756,14 +2854,14 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     hypl[t] = val;
     P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = val;
   }
-  __syncthreads();
+  lds_barrier();
+  SSTAMP();
   // ---- B: per-point factors
   const double nscal = FIT ? (F.has_noise ? thl[F.P - 1] : 0.0)
                            : P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0);
   for (int e = t; e < NB * Q; e += DIAG_THREADS) {
     const int m = e & (NB - 1), q = e >> 7;
-    const int64_t ci = (int64_t)cb * P.cstride + m;
-    const double xi = (m < n) ? P.x[ci] : 0.0;
+    const double xi = x_pre;                                    // (m == t & 127 in every round: DIAG_THREADS is a multiple of NB)
     const double mu = hypl[Q + q], v = hypl[2 * Q + q];
     double sn, cs;
     sincospi(2.0 * (xi * mu), &sn, &cs);
@@ -2774,8 +2872,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   if (t < NB) {
     const int m = t;
     const bool valid = m < n;
-    const int64_t ci = (int64_t)cb * P.cstride + m;
-    const double xi = valid ? P.x[ci] : 0.0;
+    const double xi = x_pre;
     fac[3 * Q * NB + m] = xi;
     pre[(int64_t)(3 * Q) * P.np + m] = xi;
     double mean_i;
@@ -2783,28 +2880,80 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
       mean_i = thl[F.nmean - 1];                               // the constant, or the bias of a linear mean (d = 1: one weight)
       if (F.nmean > 1) mean_i += xi * thl[0];
       if (valid) F.mean_vec[m] = mean_i;
-    } else mean_i = valid ? P.mean[ci] : 0.0;
-    const double rr = valid ? (P.y[ci] - mean_i) : 0.0;
-    const double da = valid ? ((P.noise ? P.noise[ci] : 0.0) + nscal + P.jitter) : 0.0;
+    } else mean_i = mean_pre;
+    const double rr = valid ? (y_pre - mean_i) : 0.0;
+    const double da = valid ? (nz_pre + nscal + P.jitter) : 0.0;
     rsv[m] = rr; zsv[m] = 0.0; alv[m] = 0.0; dadd[m] = da; dvec[m] = 0.0;
     const int64_t vi = (int64_t)b * P.sVec + m;
     P.r[vi] = rr; P.diagadd[vi] = da;
   }
   if (t == 0) { misc[0] = 0.0; misc[1] = 0.0; }
-  __syncthreads();
+  lds_barrier();
+  SSTAMP();
 
-  // ---- C: the factorisation (the roles of k_diag's workgroup 0)
+  // ---- C0: the sub-blocks of the upper triangle the light curve has, built by ALL 16 wavefronts into the (still unused) block image:
+  // block (i, j), i <= j < nse, at j (j + 1) / 2 + i, row-major 16 x 16 -- the MFMA C layout's LDS form (diag_put / diag_get).
+  // (The exp of the build is VALU work; the factorisation's workers sit on three of the four SIMDs and would spend 13 us on it.)
+  {
+    const LoadFromFactors build{fac, hypl, dadd, Q, n};
+    const int T = nse * (nse + 1) / 2;
+    for (int u = wave; u < T; u += 16) {
+      int i, j;
+      tri_decode(u, i, j);
+      i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
+      diag_put(M + u * DB * DB, build(DiagCtx{}, i, j, lane), lane);
+    }
+  }
+  lds_barrier();
+  SSTAMP();
+
+  // ---- C: the factorisation (the roles of k_diag's workgroup 0); D: the inverse accumulates beside it
   DiagCtx c;
   c.prow = M; c.dg = M + 2 * NS * DB * DB; c.sup = c.dg + NS * DB * DB;
   c.uiS = uiS; c.udg = udg; c.dump = dump;
   c.Akk = nullptr; c.ld = 0;
   c.Dinv0 = P.Dinv + b * P.sDinv;
   c.Dinv1 = c.Dinv0 + NB * NB;
-  const LoadFromFactors load{fac, hypl, dadd, Q, n};
+  // sub-block (i, j) from the image, or what the identity padding holds beyond the light curve's last sub-block row.
+  // (Nothing writes the image before every wavefront has taken its blocks: the chain's first LDS write is V_00 over image block
+  //  (0, 0), which only the chain reads; the workers publish block row 0 behind the step's first barrier, which they reach with
+  //  their blocks in registers.)
+  auto load = [&](const DiagCtx&, int i, int j, int ln) -> v4d {
+    if (j < nse) return diag_get(M + (j * (j + 1) / 2 + i) * DB * DB, ln);      // (i <= j)
+    v4d o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (i == j && (ln >> 4) + 4 * r == (ln & 15)) ? 1.0 : 0.0;
+    return o;
+  };
+  // A^-1 sub-block (i, j), i <= j, = sum over s >= j of V(s, i)^T V(s, j): sub-block number u = j (j + 1) / 2 + i belongs to worker
+  // u mod 12 (at every step the blocks that receive a product, j <= s, are a prefix of that order: evenly dealt), at most 3 each
+  v4d G[SMALL_MAXT];
+#pragma unroll
+  for (int k = 0; k < SMALL_MAXT; ++k) G[k] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int widx = wave - 1 - (wave >> 2);                      // worker number 0 .. 11 (workers only)
+  int ti[SMALL_MAXT], tj[SMALL_MAXT];
+#pragma unroll
+  for (int k = 0; k < SMALL_MAXT; ++k) {
+    int i = 0, j = NS;                                         // (j = NS: no such sub-block)
+    const int u = widx + DIAG_WORKERS * k;
+    if ((wave & 3) != 0 && u < NS * (NS + 1) / 2) tri_decode(u, i, j);
+    ti[k] = __builtin_amdgcn_readfirstlane(i); tj[k] = __builtin_amdgcn_readfirstlane(j);
+  }
+  auto inverse_products = [&](int s, const double* row, int ln) {
+    if (!P.need_grad) return;
+#pragma unroll
+    for (int k = 0; k < SMALL_MAXT; ++k) {
+      if (tj[k] > s) continue;                                  // (uniform)
+      const double* pa = row + ti[k] * DB * DB + ln;
+      const double* pb = row + tj[k] * DB * DB + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[64 * r], pb[64 * r], G[k], 0, 0, 0);
+    }
+  };
   if (wave == 0) {
     diag_chain(c, lane, nse, load);
   } else if ((wave & 3) != 0) {
-    diag_worker(c, wave - 1 - (wave >> 2), lane, nse, load);
+    diag_worker<decltype(load), decltype(inverse_products)&, false>(c, widx, lane, nse, load, inverse_products);
   } else if (wave == 4) {
     double lgsum = 0.0;
     int firstbad = -1;
@@ -2842,73 +2991,72 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     if (lane == 0) {
       P.logdet[b * P.sLogdet] = tot;
       misc[0] = tot;
-      misc[1] = firstbad >= 0 ? (double)(1 + firstbad) : 0.0;
+      const int info = firstbad >= 0 ? 1 + firstbad : 0;
+      misc[1] = (double)info;
+      // the status is final here: to the workspace and the caller; the host's copy follows right behind the barrier (below)
+      P.info[b] = info;
+      if (P.info_out) P.info_out[cb] = info;
     }
   } else {
     // waves 8 and 12: V_ss leaves for the two inverse images (one each)
-    const int kq = lane >> 4, nn = lane & 15;
-    for (int s = 0; s < NS; ++s) {
-      v4d v;
-      if (s < nse) {
-        lds_barrier();
-        v = diag_get(c.prow + (s & 1) * NS * DB * DB + s * DB * DB, lane);
-        lds_barrier();
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (kq + 4 * r == nn) ? 1.0 : 0.0;
-      }
-      diag_store_v(c, s, s, v, lane, wave == 8 ? 1 : 2);
+    const int which = wave == 8 ? 1 : 2;
+    for (int s = 0; s < nse; ++s) {
+      lds_barrier();
+      const v4d v = diag_get(c.prow + (s & 1) * NS * DB * DB + s * DB * DB, lane);
+      lds_barrier();
+      diag_store_v(c, s, s, v, lane, which);
     }
   }
-  __syncthreads();                                              // (every store of the inverse images has drained: vmcnt(0) in front of the barrier)
+#ifdef PGM_SMALL_STAMPS
+  if (lane == 0) stw_[wave][0] = __builtin_amdgcn_s_memtime();
+#endif
+  SSTAMP();
+  for (int e = t; e < 16 * nslot; e += DIAG_THREADS) wpart[e] = 0.0;
+  lds_barrier();                                                // (LDS only: alpha, the status; the inverse images drain in the background)
+  SSTAMP();
   const int bad = (int)misc[1];
+  // the host may be polling for the status (the Python surface's psd_safe_cholesky-style check): it gets it before the gradient
+  // epilogue, not behind it -- from the wavefront with the fewest sub-blocks to contract, and not in front of the barrier above
+  // (a system-scope fence waits for the wavefront's earlier stores: on the bookkeeper it held every wavefront up for ~2 us)
+  if (t == DIAG_THREADS - 64 && P.info_host) {
+    P.info_host[b] = bad;
+    __threadfence_system();
+    P.seq_host[b] = P.seq;
+  }
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   const double half_n = 0.5 / (double)n;
-
-  if (P.need_grad && !bad) {
-    // ---- D: V -> LDS as sub-block fragments; block (s, j), j <= s, at s (s + 1) / 2 + j, row-major 16 x 16
-    const int T = nse * (nse + 1) / 2;
-    for (int e = t; e < T * DB * DB; e += DIAG_THREADS) {
-      const int blk = e >> 8, w = e & 255;
-      int jj, ss;
-      tri_decode(blk, jj, ss);
-      M[e] = c.Dinv1[(ss * DB + (w >> 4)) * NB + jj * DB + (w & 15)];
-    }
-    for (int e = t; e < 16 * nslot; e += DIAG_THREADS) wpart[e] = 0.0;
-    __syncthreads();
-    // A^-1 sub-block (i, j), i <= j:  sum over s >= j of V(s, i)^T V(s, j)
-    v4d G[SMALL_MAXT];
-    int ti[SMALL_MAXT], tj[SMALL_MAXT];
+  const bool grad = P.need_grad && !bad;
+  // The gradient epilogue is VALU work (one exp per pair and mixture): the A^-1 sub-blocks go from the twelve workers, which sit on
+  // three of the four SIMDs, through the block image (free again) to all sixteen wavefronts
+  const int T = nse * (nse + 1) / 2;
+  if (grad && (wave & 3) != 0) {
+#pragma unroll
+    for (int k = 0; k < SMALL_MAXT; ++k)
+      if (tj[k] < nse) diag_put(M + (widx + DIAG_WORKERS * k) * DB * DB, G[k], lane);
+  }
+  lds_barrier();
+  if (grad) {
+    // ---- E: G = weight * (alpha alpha^T - A^-1) on the valid pairs, the diagonal of A^-1 for the noise gradient, and the contraction
+    // with dK/d(w, mu, v) (the 1-D epilogue of lauum_grad_item on 16 x 16 sub-blocks)
     int nt = 0;
 #pragma unroll
     for (int k = 0; k < SMALL_MAXT; ++k) {
       const int u = wave + 16 * k;
-      G[k] = v4d{0.0, 0.0, 0.0, 0.0};
-      ti[k] = 0; tj[k] = 0;
-      if (u < T) {
-        int i, j;
-        tri_decode(u, i, j);
-        i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
-        ti[k] = i; tj[k] = j; nt = k + 1;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        for (int s2 = j; s2 < nse; ++s2) {
-          const double* pa = M + (s2 * (s2 + 1) / 2 + i) * DB * DB + lane;
-          const double* pb = M + (s2 * (s2 + 1) / 2 + j) * DB * DB + lane;
+      int i = 0, j = NS;
+      if (u < T) tri_decode(u, i, j);
+      ti[k] = __builtin_amdgcn_readfirstlane(i); tj[k] = __builtin_amdgcn_readfirstlane(j);
+      if (u >= T) continue;
+      nt = k + 1;
+      G[k] = diag_get(M + u * DB * DB, lane);
+      const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
+      const double wt = (ti[k] == tj[k]) ? 1.0 : 2.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[64 * r], pb[64 * r], acc, 0, 0, 0);
-        }
-        // G = weight * (alpha alpha^T - A^-1) on the valid pairs; the diagonal of A^-1 for the noise gradient
-        const int g = lane >> 4, col = j * DB + (lane & 15);
-        const double wt = (i == j) ? 1.0 : 2.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = i * DB + g + 4 * r;
-          if (i == j && m == col) dvec[m] = acc[r];
-          G[k][r] = (m < n && col < n) ? wt * (alv[m] * alv[col] - acc[r]) : 0.0;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int m = ti[k] * DB + g + 4 * r;
+        if (ti[k] == tj[k] && m == col) dvec[m] = G[k][r];
+        G[k][r] = (m < n && col < n) ? wt * (alv[m] * alv[col] - G[k][r]) : 0.0;
       }
     }
-    // ---- E: the contraction with dK/d(w, mu, v) (the 1-D epilogue of lauum_grad_item on 16 x 16 sub-blocks)
     const double* xs = fac + 3 * Q * NB;
     double* mypart = wpart + wave * nslot;
 #pragma unroll 1
@@ -2917,7 +3065,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
       double gw = 0.0, gmu = 0.0, gv = 0.0;
 #pragma unroll
       for (int k = 0; k < SMALL_MAXT; ++k) {
-        if (k >= nt) continue;
+        if (k >= nt || tj[k] >= nse) continue;
         const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
         const double cc_ = rq[col], cs_ = rq[NB + col], cv = rq[2 * NB + col], cx = xs[col];
 #pragma unroll
@@ -2935,11 +3083,13 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
           gv = __builtin_fma(tt, CC * tau, gv);
         }
       }
-      gw = wave_sum(gw); gmu = wave_sum(gmu); gv = wave_sum(gv);
+      gw = wave_sum_dpp(gw); gmu = wave_sum_dpp(gmu); gv = wave_sum_dpp(gv);
       if (lane == 0) { mypart[q] = gw; mypart[Q + q] = gmu; mypart[2 * Q + q] = gv; }
     }
-    __syncthreads();
   }
+  SSTAMP();
+  lds_barrier();
+  SSTAMP();
 
   // ---- F: results.  (A failed factorisation leaves NaN in every output, as k_finalize does.)
   if (wave == 0) {
@@ -2956,13 +3106,6 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
       outs[0] = val;
       P.out_small[b * P.sOut] = val;
       if (P.mll) P.mll[cb] = val;
-      P.info[b] = bad;
-      if (P.info_out) P.info_out[cb] = bad;
-      if (P.info_host) {
-        P.info_host[b] = bad;
-        __threadfence_system();
-        P.seq_host[b] = P.seq;
-      }
     }
   }
   if (P.need_grad) {
@@ -2993,9 +3136,36 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
       }
     }
   }
+  SSTAMP();
   if (FIT) {
-    __syncthreads();
-    fit_post_body<DIAG_THREADS>(F, outs, outs + 1, outs + 1 + Q, outs + 1 + 2 * Q, gno, gme, red, sums);
+    lds_barrier();
+    fit_post_body<DIAG_THREADS>(F, L, outs, outs + 1, outs + 1 + Q, outs + 1 + 2 * Q, gno, gme, red, sums);
+  }
+  SSTAMP();
+#ifdef PGM_SMALL_STAMPS
+  __syncthreads();
+  if (t == 0 && b == 0) {
+    printf("k_small n=%d nse=%d q=%d ticks: ", n, nse, Q);
+    for (int k = 1; k < ssn_; ++k) printf("%d ", (int)(sst_[k] - sst_[0]));
+    printf("| role done (wave:ticks): ");
+    for (int w = 0; w < 16; ++w) printf("%d:%d ", w, (int)(stw_[w][0] - sst_[0]));
+    printf("\n");
+  }
+#endif
+#undef SSTAMP
+}
+
+// The identity padding of the inverse images of a light curve k_small evaluated (workspace slot 0): rows / columns of the
+// sub-blocks beyond its last one.  Launched by pgm_predict_f64 in front of its right-hand-side solve.
+__global__ __launch_bounds__(256) void k_small_pad(PgmDev P) {
+  const int nse = (P.n + DB - 1) / DB, first = nse * DB;
+  double* inv0 = P.Dinv;                // [p][m] = V[m][p]
+  double* inv1 = P.Dinv + NB * NB;      // [k][n] = V[k][n]
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < (NB - first) * NB; e += gridDim.x * 256) {
+    const int k = first + e / NB, c = e % NB;          // row k >= first of V: zero but for the diagonal
+    const double val = (k == c) ? 1.0 : 0.0;
+    inv1[k * NB + c] = val;
+    inv0[c * NB + k] = val;
   }
 }
 

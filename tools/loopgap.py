@@ -1,7 +1,7 @@
 """Where the GPU idles between two iterations of the reference-shaped loop (N points): host time from the return of
 loss.cpu() to the next evaluation's launch, phase by phase.   python tools/loopgap.py [n]"""
 import sys, time, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pgmuvi_amd import gpytorch as g, synthetic as syn, _hip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")

@@ -52,7 +52,7 @@ def rate(n, q, B, reps):
 
 
 res = {}
-for sw in ("1", "0"):
+for sw in (os.environ.get("SMALLBENCH_ORDER", "1,0").split(",")):
     os.environ["PGM_SMALL"] = sw
     _hip.release_workspaces()
     r = {"reference_published_workload": bench.reference_published_workload(dev)}
