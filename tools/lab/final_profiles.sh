@@ -3,7 +3,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-part=${1:-ab}
+part=${1:-abc}
 if [[ $part == *a* ]]; then
 bash tools/profile.sh single_n4096 4096 5 1
 bash tools/profile.sh cfg4_n8192_d2 8192 3 1 3 1 2
@@ -25,3 +25,15 @@ k=$(find gpurun_out/prof_ragged512 -name 'stats_kernel_trace.csv' | head -1); py
 find gpurun_out/prof_ragged512 -name '*_kernel_trace.csv' -delete
 fi
 sha256sum pgmuvi_amd/libpgmuvi_hip.so > gpurun_out/prof_lib_sha.txt
+if [[ $part == *c* ]]; then
+# round 6: the one-launch path (k_small) -- kernel statistics of the reference's published workload through train_native and of
+# plain evaluations at N = 17 / 89 / 128, and the in-kernel phase timeline of the lab build with -DPGM_SMALL_STAMPS (tools/variants/stamps)
+mkdir -p gpurun_out/prof_small
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_small -o stats -- python3 tools/smallprof.py > gpurun_out/prof_small/stats.log 2>&1
+s=$(find gpurun_out/prof_small -name 'stats_kernel_stats.csv' | head -1); head -4 "$s" > gpurun_out/prof_small/kernel_stats.csv
+find gpurun_out/prof_small -name '*_kernel_trace.csv' -delete
+if [ -f tools/variants/stamps/libpgmuvi_hip.so ]; then
+  ( export LD_LIBRARY_PATH=$PWD/tools/variants/stamps:$LD_LIBRARY_PATH
+    for a in "1 2 1 2" "17 2 1 2" "89 2 1 2" "89 2 0 2" "89 2 1 4" "128 2 1 2" "128 2 1 4"; do tools/evalloop $a 2>&1 | grep k_small | tail -1; done ) > gpurun_out/prof_small/phase_ticks.txt 2>&1
+fi
+fi

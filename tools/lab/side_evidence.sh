@@ -9,6 +9,9 @@ export LD_LIBRARY_PATH=$PWD/pgmuvi_amd:$LD_LIBRARY_PATH
 python3 bench.py --steps 20 --warmup 5 > $o/bench_line.json 2> $o/bench.err
 python3 bench.py --total-batch 512 --npoints 2048 --steps 5 --warmup 2 > $o/bench_line_total_batch512_n2048.json 2> $o/bench_total.err
 python3 tools/trainbench.py > $o/trainbench.txt 2>&1
+python3 tools/smallbench.py > $o/smallbench.json 2> $o/smallbench.err
+( for sw in 1 0; do echo "PGM_SMALL=$sw"; for n in 1 17 64 89 128; do PGM_SMALL=$sw tools/evalloop $n 2000 1 2; done; PGM_SMALL=$sw tools/evalloop 89 2000 1 4; PGM_SMALL=$sw tools/evalloop 128 2000 1 4; PGM_SMALL=$sw tools/evalloop 89 2000 0 2; done ) > $o/evalloop_small_ab.txt 2>&1
+for n in 8320 12288 16384; do tools/evalloop $n 3 1; done > $o/evalloop_beyond64.txt 2>&1
 python3 tools/configbench.py > $o/configbench.txt 2>&1
 python3 tools/batchbench.py > $o/batchbench.txt 2>&1
 python3 tools/densebench.py > $o/densebench.txt 2>&1
