@@ -121,6 +121,12 @@ int pgm_mll_value_grad_f64(pgm_ws* ws, const double* x, const double* y, const d
  * batch x q, ..., mll: batch, info: batch); `noise_scalar` may be NULL or a
  * device array of `batch` values.  All problems advance together, one launch
  * per algorithm step with the batch on gridDim.z.
+ *
+ * Light curves of at most 128 points (1-D inputs; pgmuvi's one published workload has 89, paper/paper.md:113): the whole
+ * evaluation -- factors, matrix, factorisation, inverse, gradient contraction, results, status -- is ONE launch, one
+ * workgroup per light curve (k_small); no launch graph, nothing but the results and what pgm_predict_f64 reads later is
+ * written to memory.  Same results as the launch sequence of every other size (value: the same bits; gradients: 1e-12),
+ * which the environment switch PGM_SMALL=0 (read when a workspace is made) brings back.
  */
 int pgm_mll_value_grad_batched_f64(pgm_ws* ws, int batch,
                                    const double* x, const double* y, const double* mean,
@@ -201,7 +207,9 @@ int64_t pgm_profile_early_inverse_products(const pgm_ws* ws);
  * semantics).  x, y, noise are device pointers that must outlive the handle; raw0 / ckind / ca / cb are host arrays.
  * pgm_fit_run enqueues `iters` more iterations; pgm_fit_read synchronises and returns the iterations done, the loss
  * -mll per iteration, the raw parameters after each step ([iters][P]), the current raw parameters and the last
- * factorisation status.
+ * factorisation status (the device writes this log to host-mapped memory as it goes: a read is a stream synchronisation
+ * and host copies).  For n <= 128 (d = 1) an iteration is ONE launch -- constraint transforms, the evaluation, the chain
+ * rule and the optimiser step inside k_small -- replayed 25 iterations per graph.
  * pgm_fit_set_priors (optional, before the first pgm_fit_run): MAP instead of maximum likelihood -- per raw-vector entry
  * a prior on the CONSTRAINED value, kind 0 none, 1 Normal(loc, scale), 2 LogNormal(loc, scale) (the priors
  * pgmuvi/lightcurve.py:3273-3322 registers); their log densities are added to N * mll before the division by N, as

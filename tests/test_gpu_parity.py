@@ -495,6 +495,30 @@ def test_posterior_prediction_vs_oracle(dev, golden_dir):
     assert torch.allclose((hi - lo).cpu(), 4 * pv.clamp_min(0).sqrt(), atol=1e-7)
 
 
+@pytest.mark.parametrize("n", [1, 40, 89, 128])
+def test_prediction_after_a_one_launch_evaluation(dev, n):
+    """``pgm_predict_f64`` behind k_small: the one-launch evaluation does not write the identity padding of the diagonal block's
+    inverse images (rows of sub-blocks the light curve does not have), prediction completes it (k_small_pad) -- here with STALE
+    values there on purpose: a 128-point evaluation on the same workspace first.  Posterior mean and variance against the oracle."""
+    _hip.release_workspaces()
+    ws = _hip.Workspace(dev, 128, 2, 1, 1)
+    gen = torch.Generator().manual_seed(50 + n)
+    w = torch.tensor([0.6, 0.3], dtype=D); mu = torch.tensor([[0.02], [0.11]], dtype=D); v = torch.tensor([[0.003], [0.01]], dtype=D)
+    for m in (128, n):
+        x = torch.sort(torch.rand(m, generator=gen, dtype=D) * 300)[0]
+        y = torch.randn(m, generator=gen, dtype=D)
+        noise = 0.01 + 0.05 * torch.rand(m, generator=gen, dtype=D)
+        out = _hip.mll_value_grad(x.reshape(m, 1).to(dev), y.to(dev), torch.full((m,), 0.2, dtype=D, device=dev), noise.to(dev), None,
+                                  w.to(dev), mu.to(dev), v.to(dev), 0, 0.0, True, workspace=ws)
+        assert int(out["info"]) == 0
+    xs = torch.linspace(-10.0, 310.0, 257, dtype=D)
+    pm, pv = _hip.predict(ws, xs.reshape(-1, 1).to(dev), torch.full((257,), 0.2, dtype=D, device=dev))
+    torch.cuda.synchronize()
+    rm, rv = orc.posterior(x, y, 0.2, noise, w, mu, v, xs, 0.2)
+    assert torch.allclose(pm.cpu(), rm, atol=1e-9) and torch.allclose(pv.cpu(), rv, atol=1e-9)
+    ws.close()
+
+
 def test_posterior_prediction_at_the_reference_size(dev):
     """Eval-mode prediction the way ``Lightcurve.plot()`` / ``to_table()`` ask for it (/root/reference/pgmuvi/lightcurve.py:9607-9623:
     ``torch.linspace(x.min(), x.max(), 10000)`` under ``fast_pred_var``) at the headline size: N = 4096 training points (config 2's

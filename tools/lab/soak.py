@@ -91,3 +91,69 @@ for rep in range(40):
         elif first[name] != r: bad += 1; print("POTENTIAL MISMATCH", rep, name)
 torch.cuda.synchronize()
 print(f"potential soak: 160 calls (one-chain tick, plain N=2048 evaluation, eight-chain tick, 12 x N=1024 batch, alternating on shared workspaces) in {time.time() - t0:.1f} s, {bad} mismatches")
+
+# round 6: the one-launch path (k_small) interleaved with everything around it on shared cached workspaces -- single short light curves,
+# a batch of them, a ragged batch of short ones, a device-resident fit advancing between the others, a potential on short light curves,
+# prediction after a short evaluation -- every repeat bit for bit the first result
+from pgmuvi_amd.batch import evaluate_ragged as _er
+small_sizes = [1, 17, 64, 89, 100, 128]
+sd = {}
+for n in small_sizes:
+    t, y, e = syn.cfg2(n_obs=n); hh = syn.cfg_hypers(2, y.double())
+    sd[n] = (t.double().reshape(-1, 1).to(dev), y.double().to(dev), torch.full((n,), float(hh["mean"]), dtype=D, device=dev), (e.double() ** 2).to(dev),
+             hh["w"].to(dev), hh["mu"].reshape(4, 1).to(dev), hh["v"].reshape(4, 1).to(dev))
+Bs, ns_ = 37, 100
+xs2, ys2, nz2 = chains(Bs, ns_)
+hb = syn.cfg_hypers(2, ys2[0].cpu())
+wb2, mub2, vb2 = (t.to(dev).expand(Bs, *t.shape).contiguous() for t in (hb["w"], hb["mu"].reshape(4, 1), hb["v"].reshape(4, 1)))
+rag_curves = []
+for i, n in enumerate([5, 128, 33, 97, 64, 120, 12, 77, 101, 128, 50, 88, 19, 127]):
+    (t, y, e), per = syn.cfg3_lightcurve(i, n_obs=n)
+    hh = syn.cfg_hypers(3, y.double(), lead_period=per)
+    rag_curves.append(dict(x=t.double(), y=y.double(), noise=e.double() ** 2, mean=hh["mean"], w=hh["w"], mu=hh["mu"], v=hh["v"]))
+rag_padded = pad_curves(rag_curves, device=dev)
+xp1, yp1, np1 = chains(3, 96)
+pot_s = mcmc.SMPotential(xp1, yp1, np1, num_mixtures=4)
+zs = zfor(pot_s)
+from pgmuvi_amd import gpytorch as g
+from pgmuvi_amd.trainers import train_native
+def fit_once():
+    x, y, m, nz, w, mu, v = sd[89]
+    lik = g.likelihoods.FixedNoiseGaussianLikelihood(nz)
+    class M(g.models.ExactGP):
+        def __init__(s):
+            super().__init__(x.reshape(-1), y, lik); s.mean_module = g.means.ConstantMean(); s.covar_module = g.kernels.SpectralMixtureKernel(num_mixtures=4)
+        def forward(s, xx): return g.distributions.MultivariateNormal(s.mean_module(xx), s.covar_module(xx))
+    mm = M().double().to(dev)
+    mm.initialize(**{"covar_module.mixture_weights": w, "covar_module.mixture_means": mu.reshape(4, 1, 1), "covar_module.mixture_scales": v.reshape(4, 1, 1)})
+    r = train_native(model=mm, likelihood=lik, train_x=x.reshape(-1), train_y=y, maxiter=60, lr=0.01, optim="AdamW", stop=None, check_every=25)
+    return tuple(float(v_) for v_ in r["loss"])
+def one(n):
+    x, y, m, nz, w, mu, v = sd[n]
+    o = _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True)
+    return (float(o["mll"]), float(o["g_w"].sum()), float(o["g_noise"].sum()), int(o["info"]))
+def batch_small():
+    o = _hip.mll_value_grad(xs2, ys2, torch.zeros(Bs, ns_, dtype=D, device=dev), nz2, None, wb2, mub2, vb2, 0, 0.0, True)
+    return (float(o["mll"].sum()), float(o["g_mu"].sum()), int(o["info"].abs().max()))
+def rag_small():
+    p, lens = rag_padded
+    o = _hip.mll_value_grad_ragged(p["x"], p["y"], p["mean"], p["noise"], None, lens, p["w"], p["mu"], p["v"], 0, 0.0, True)
+    return (float(o["mll"].sum()), float(o["g_mu"].sum()), int(o["info"].abs().max()))
+def predict_small():
+    x, y, m, nz, w, mu, v = sd[89]
+    o = _hip.mll_value_grad(x, y, m, nz, None, w, mu, v, 0, 0.0, True)
+    xt = torch.linspace(float(x.min()), float(x.max()), 300, dtype=D, device=dev).reshape(-1, 1)
+    pm, pv = _hip.predict(o["workspace"], xt, torch.zeros(300, dtype=D, device=dev))
+    return (float(pm.sum()), float(pv.sum()))
+first, bad, calls = {}, 0, 0
+t0 = time.time()
+jobs = [(f"n{n}", (lambda n=n: one(n))) for n in small_sizes] + [("batch37x100", batch_small), ("ragged14", rag_small), ("pot3x96", lambda: tuple(np.concatenate([a.ravel() for a in pot_s(zs)]))),
+        ("predict89", predict_small), ("plain2048", plain), ("fit89", fit_once)]
+for rep in range(25):
+    for name, f in jobs:
+        if name == "fit89" and rep % 5: continue
+        r = f(); calls += 1
+        if name not in first: first[name] = r
+        elif first[name] != r: bad += 1; print("SMALL-PATH MISMATCH", rep, name)
+torch.cuda.synchronize()
+print(f"one-launch path soak: {calls} calls ({', '.join(n for n, _ in jobs)}; alternating on shared cached workspaces) in {time.time() - t0:.1f} s, {bad} mismatches")
