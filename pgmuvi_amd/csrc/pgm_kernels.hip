@@ -599,7 +599,10 @@ struct NoRowHook {
 
 // a worker wavefront: its sub-blocks through all steps.  (The slot table stays packed in one scalar register pair and is
 // decoded where it is used: two dozen wave-uniform integers kept live across the loop made the compiler spill scalars.)
-template <class Load = LoadFromMatrix, class Hook = NoRowHook, bool PAD_STORES = true>
+// PAD_STORES false / SKIP_PAD true (k_small): the sub-blocks of the identity padding -- rows and columns beyond the light curve's
+// last sub-block row, zero or identity for good -- are neither solved, published, updated nor stored (k_diag runs their
+// arithmetic on zeros and stores them: the block row's image and the inverse images are read whole by the kernels behind it).
+template <class Load = LoadFromMatrix, class Hook = NoRowHook, bool PAD_STORES = true, bool SKIP_PAD = false>
 __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, int nse, const Load load = Load(), Hook&& hook = Hook()) {
   constexpr int NS = NB / DB;
   const unsigned long long pack = *reinterpret_cast<const unsigned long long*>(DIAG_OWN[q]);
@@ -617,15 +620,11 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
 #pragma unroll
     for (int t = 0; t < DIAG_SLOTS; ++t) {
       const int e = SLOT_E(t), i = e >> 4, j = e & 15;
-      if (i == s && j != s) {                                  // my block of block row s: solve, publish
+      if (i == s && j != s && (!SKIP_PAD || j < nse)) {        // my block of block row s: solve, publish
         acc[t] = diag_solve(c, acc[t], lane);
         diag_put(row + j * DB * DB, acc[t], lane);
       }
     }
-    // (the hook's work on block row s-1 -- its image, the other parity, stays until row s+1 is published -- goes HERE: between
-    //  the two barriers of a step the workers wait for the chain, which solves, updates and factors a mini-panel before it meets
-    //  the second one; behind the updates below it would delay the next step's first barrier: k_small, +7 .. 12 % on the chain)
-    if (s > 0) hook(s - 1, c.prow + ((s - 1) & 1) * NS * DB * DB, lane);
     lds_barrier();                                             // block row s is in LDS
 #pragma unroll
     for (int t = 0; t < DIAG_SLOTS; ++t) {
@@ -633,7 +632,7 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
       // steps whose block row is applied to this block: U (i < j): 0 .. i-1;  V (i > j): j .. i-1 (it is zero before);
       // diagonal: 0 .. i-2 (the chain applies i-1 itself);  none: never
       const int lo = (i > j) ? j : 0, hi = (e == 0xff) ? 0 : (i == j) ? i - 1 : i;
-      if (s >= lo && s < hi) {                                 // C(i,j) -= U(s,i)^T B(s,j);  B is U(s,j) (j>s), V(s,j) (j<s) or V_ss
+      if (s >= lo && s < hi && (!SKIP_PAD || (i < nse && j < nse))) {     // C(i,j) -= U(s,i)^T B(s,j);  B is U(s,j) (j>s), V(s,j) (j<s) or V_ss
         const double* pa = row + i * DB * DB + lane;
         const double* pb = row + j * DB * DB + lane;
         double a[4], b[4];
@@ -650,10 +649,14 @@ __device__ __forceinline__ void diag_worker(const DiagCtx& c, int q, int lane, i
       const int e = SLOT_E(t), i = e >> 4, j = e & 15;
       if (i == s && j < s) diag_store_v(c, s, j, acc[t], lane);
     }
+    // (the hook's work on block row s goes behind the step's updates: early steps have many updates and few products of the
+    //  inverse, late steps the other way round.  Between the step's two barriers instead -- on block row s-1, whose image stays
+    //  until row s+1 is published -- it held the chain up at the second barrier: same-box A/B in k_small, N=89 52.7k against
+    //  50.0k clock ticks to the end of the chain, 74.6k / 73.9k for the kernel; N=128 108.0k / 107.0k)
+    hook(s, row, lane);
   }
-  if (nse > 0) hook(nse - 1, c.prow + ((nse - 1) & 1) * NS * DB * DB, lane);
   // block rows of identity padding (the last diagonal block of a light curve whose length is no multiple of 128): zero blocks
-  // (PAD_STORES false, k_small: two otherwise idle wavefronts write them, off the workers' path)
+  // (PAD_STORES false, k_small: prediction, the only reader of a single block's inverse images, completes them itself)
   if constexpr (PAD_STORES) {
 #pragma unroll
     for (int t = 0; t < DIAG_SLOTS; ++t) {
@@ -2785,7 +2788,7 @@ constexpr int SMALL_MAXT = 3;                                  // sub-blocks of 
 constexpr int SMALL_VIMG = (NB / DB) * (NB / DB + 1) / 2 * DB * DB;   // 36 sub-blocks of 256
 // doubles of dynamic LDS
 __host__ __device__ constexpr int small_lds_doubles(int q) {
-  return SMALL_VIMG + (3 * q + 1) * NB + DB * DB + 8 * NB + 64 + 64 + 3 * PGM_MAX_QD + 64 + 8 + 16 * (3 * PGM_MAX_QD + 1) + 256 + 8;
+  return SMALL_VIMG + (3 * q + 1) * NB + DB * DB + 8 * NB + 64 + 64 + 3 * PGM_MAX_QD + 64 + 8 + 16 * (3 * PGM_MAX_QD + 1) + 256 + 8 + 10 * 64;
 }
 
 template <bool FIT>
@@ -2814,6 +2817,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   double* wpart = misc + 8;                         // [16][nslot]
   double* red = wpart + 16 * (3 * PGM_MAX_QD + 1);  // [256] (FIT)
   double* sums = red + 256;                         // [8]   (FIT)
+  double* fitl = sums + 8;                          // [10][64] (FIT) what the optimiser step reads from memory, parked here meanwhile
   const int cb = caller_slot(P, b), n = pts(P, b);
   const int nse = __builtin_amdgcn_readfirstlane((n + DB - 1) / DB);
   double* pre = P.pre + b * P.sPre;
@@ -2839,9 +2843,14 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     if (!FIT) mean_pre = P.mean[ci];
   }
   // ---- A: the mixture's parameters
-  FitLoads L;
   if (FIT) {
-    L = fit_loads(F);                                           // (everything the optimiser step at the end reads from memory, now)
+    // (everything the optimiser step at the end reads from memory is requested now and parked in LDS: twenty registers per lane
+    //  held across the whole kernel made the compiler spill)
+    const FitLoads L = fit_loads(F);
+    if (t < 64) {
+      fitl[0 * 64 + t] = L.raw; fitl[1 * 64 + t] = L.ca; fitl[2 * 64 + t] = L.cb; fitl[3 * 64 + t] = L.ploc; fitl[4 * 64 + t] = L.pscale;
+      fitl[5 * 64 + t] = L.m1; fitl[6 * 64 + t] = L.m2; fitl[7 * 64 + t] = (double)L.ckind; fitl[8 * 64 + t] = (double)L.pkind; fitl[9 * 64 + t] = (double)L.it;
+    }
     if (t < F.P) { const double th = fit_theta_of(L); thl[t] = th; F.theta[t] = th; if (F.has_noise && t == F.P - 1) F.noise_scalar[0] = th; }
     lds_barrier();
   }
@@ -2893,7 +2902,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
 
   // ---- C0: the sub-blocks of the upper triangle the light curve has, built by ALL 16 wavefronts into the (still unused) block image:
   // block (i, j), i <= j < nse, at j (j + 1) / 2 + i, row-major 16 x 16 -- the MFMA C layout's LDS form (diag_put / diag_get).
-  // (The exp of the build is VALU work; the factorisation's workers sit on three of the four SIMDs and would spend 13 us on it.)
+  // (The exp of the build is VALU work; the factorisation's workers sit on three of the four SIMDs and would spend 13 us on it.
+  //  Measured and not kept: the chain factoring sub-block (0, 0) beside the build instead of behind it -- the build's wavefronts on
+  //  the chain's SIMD slow that factorisation down by more than it gains: N=89 75.0k against 74.3k clock ticks, N=128, Q=4 131.3k / 128.7k.)
   {
     const LoadFromFactors build{fac, hypl, dadd, Q, n};
     const int T = nse * (nse + 1) / 2;
@@ -2953,7 +2964,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   if (wave == 0) {
     diag_chain(c, lane, nse, load);
   } else if ((wave & 3) != 0) {
-    diag_worker<decltype(load), decltype(inverse_products)&, false>(c, widx, lane, nse, load, inverse_products);
+    diag_worker<decltype(load), decltype(inverse_products)&, false, true>(c, widx, lane, nse, load, inverse_products);
   } else if (wave == 4) {
     double lgsum = 0.0;
     int firstbad = -1;
@@ -2970,6 +2981,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int colg = lane + 64 * u, jb = colg / DB;
+        if (jb >= nse) continue;                                 // (columns of the identity padding: their blocks are not published)
         double acc = 0.0;
 #pragma unroll
         for (int m = 0; m < DB; ++m) acc += row[jb * DB * DB + m * DB + (colg - jb * DB)] * zsv[s * DB + m];
@@ -3139,6 +3151,10 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   SSTAMP();
   if (FIT) {
     lds_barrier();
+    FitLoads L;
+    const int tl = t & 63;                                      // (P <= 51 parameters: wavefront 0 holds them; the others only need `it`)
+    L.raw = fitl[0 * 64 + tl]; L.ca = fitl[1 * 64 + tl]; L.cb = fitl[2 * 64 + tl]; L.ploc = fitl[3 * 64 + tl]; L.pscale = fitl[4 * 64 + tl];
+    L.m1 = fitl[5 * 64 + tl]; L.m2 = fitl[6 * 64 + tl]; L.ckind = (int)fitl[7 * 64 + tl]; L.pkind = (int)fitl[8 * 64 + tl]; L.it = (int)fitl[9 * 64 + tl];
     fit_post_body<DIAG_THREADS>(F, L, outs, outs + 1, outs + 1 + Q, outs + 1 + 2 * Q, gno, gme, red, sums);
   }
   SSTAMP();
