@@ -271,34 +271,91 @@ __device__ __forceinline__ void build_part_1d(const PgmDev& P, const double* row
     }
 }
 
+// ---------------------------------------------------------------------------
+// Device-resident fit (SURVEY.md section 8f row 2): one optimiser iteration of pgmuvi/trainers.py:177-195 --
+// constraint transforms, the evaluation above, the chain rule back to the raw parameters, the SGD / Adam / AdamW
+// update, the loss and parameter log -- is two small kernels around the evaluation's launch sequence, all of it one
+// hipGraph replayed per iteration with no host work in between.  Raw parameter vector (P entries):
+//   [ mean: constant, or d weights + bias (linear) | w (Q) | mu (Q d) | v (Q d) | (learned scalar noise) ].
+// ---------------------------------------------------------------------------
+struct FitDev {
+  int P, n, d, q, qd, nmean, has_noise, optimizer, max_iter;      // nmean: 1 (constant mean) or d+1 (linear); optimizer: 0 SGD, 1 Adam, 2 AdamW
+  const double* x;      // [n][d] (linear mean)
+  double lr, beta1, beta2, eps, weight_decay;
+  double* raw;          // [P] in/out
+  const int* ckind;     // [P] 0 none, 1 softplus + lb, 2 ub - softplus(-raw), 3 lb + span sigmoid(raw)
+  const double* ca;     // [P] lb (kinds 1, 3) or ub (kind 2)
+  const double* cb;     // [P] span (kind 3)
+  double* theta;        // [P] constrained values of this iteration
+  double* mean_vec;     // [n]
+  double* noise_scalar; // [1]
+  double* m1;           // [P] Adam first moment
+  double* m2;           // [P] Adam second moment
+  int* it;              // [1] iterations done so far
+  int* it_host;         // host-mapped copy of it (+ [1]: the evaluation's status, written by the evaluation itself): the host reads the log without a device copy
+  double* loss_hist;    // [max_iter]
+  double* raw_hist;     // [max_iter][P] raw parameters after each step
+  // priors on the constrained parameters (MAP): the reference's ExactMarginalLogLikelihood adds sum log p(theta) before the
+  // division by N (pgmuvi/lightcurve.py:3273-3322 registers Normal and LogNormal priors)
+  const int* pkind;     // [P] 0 none, 1 Normal(loc, scale), 2 LogNormal(loc, scale)
+  const double* ploc;   // [P]
+  const double* pscale; // [P]
+};
+
+__device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+__device__ __forceinline__ double fit_theta(const FitDev& F, int p) {
+  const double r = F.raw[p];
+  if (F.ckind[p] == 1) return softplus_d(r) + F.ca[p];
+  if (F.ckind[p] == 2) return F.ca[p] - softplus_d(-r);
+  if (F.ckind[p] == 3) return sigmoid_d(r) * F.cb[p] + F.ca[p];
+  return r;
+}
+
 // Short light curves (one of at most 55 tiles, 1-D): per-point factors and kernel matrix in ONE launch in front of the graph --
 // an evaluation of N = 89 points is five dependent launches of which the first two do microseconds of work.  A workgroup
 // computes the factors of its tile's 128 rows and 128 columns itself, straight from the caller's arrays into LDS (4 sincospi per
 // thread at Q = 4) and builds its sixteenth of the tile from them (build_part_1d, the code of k_build); the workgroups of the
 // diagonal tiles also leave their block row's factors, residual and diagonal addend in the workspace, where the later
 // kernels expect what k_precompute writes -- the same expressions, hence the same bits.
-__global__ __launch_bounds__(256) void k_prebuild(PgmDev P) {
+// FIT (pgm_fit_*: the device-resident optimiser loop): the constrained parameters come from the raw vector -- every workgroup
+// transforms the (at most 51) parameters for itself, workgroup 0 leaves them in F.theta for the step at the end of the iteration --
+// and the mean is the constant (or linear) mean module's: k_fit_pre, k_precompute and k_build in one launch.
+template <bool FIT>
+__global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
   constexpr int SPLIT = BUILD_SPLIT_SMALL;
   const int b = blockIdx.z, t = threadIdx.x;
   const int part = blockIdx.x % SPLIT;
   int ib, jb;
   tri_decode(blockIdx.x / SPLIT, ib, jb);
-  extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD + NB doubles
+  extern __shared__ __attribute__((aligned(16))) double sm[];      // 2*pre_slots*NB + PGM_MAX_QD + NB (+ 64: FIT) doubles
   double* rowd = sm;
   double* cold = sm + P.pre_slots * NB;
   double* wl = cold + P.pre_slots * NB;
   double* dloc = wl + PGM_MAX_QD;
+  double* thl = dloc + NB;                                      // [64] (FIT) constrained parameters
   const int cb = caller_slot(P, b), n = pts(P, b);
   if (blockIdx.x == 0 && t == 0) P.info[b] = 0;
   publish_output_pointers(P);
-  if (blockIdx.x == 0 && t < P.q + 2 * P.qd) {
-    double val;
-    if (t < P.q) val = P.w[(int64_t)cb * P.q + t];
-    else if (t < P.q + P.qd) val = P.mu[(int64_t)cb * P.qd + (t - P.q)];
-    else val = P.v[(int64_t)cb * P.qd + (t - P.q - P.qd)];
-    P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = val;
+  if (FIT) {
+    if (t < F.P) {
+      const double th = fit_theta(F, t);
+      thl[t] = th;
+      if (blockIdx.x == 0) { F.theta[t] = th; if (F.has_noise && t == F.P - 1) F.noise_scalar[0] = th; }
+    }
+    __syncthreads();
   }
-  if (t < P.q) wl[t] = P.w[(int64_t)cb * P.q + t];
+  // parameter s of [w (q) | mu (q) | v (q)] (d = 1)
+  auto hyper = [&](int s3) -> double {
+    if (FIT) return thl[F.nmean + s3];
+    if (s3 < P.q) return P.w[(int64_t)cb * P.q + s3];
+    if (s3 < 2 * P.q) return P.mu[(int64_t)cb * P.qd + (s3 - P.q)];
+    return P.v[(int64_t)cb * P.qd + (s3 - 2 * P.q)];
+  };
+  const double nscal = FIT ? (F.has_noise ? thl[F.P - 1] : 0.0) : P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0);
+  if (blockIdx.x == 0 && t < P.q + 2 * P.qd) P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = hyper(t);
+  if (t < P.q) wl[t] = hyper(t);
   const bool writer = (ib == jb) && part == 0;                  // (uniform) this workgroup leaves block row ib's per-point values behind
   double* pre = P.pre + b * P.sPre;
   // points of the row block (side 0) and of the column block (side 1): one (point, side) per thread and round
@@ -311,7 +368,7 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P) {
     double* fac = side ? cold : rowd;
     fac[3 * P.q * NB + m] = xi;
     for (int q = 0; q < P.q; ++q) {
-      const double mu = P.mu[(int64_t)cb * P.qd + q], v = P.v[(int64_t)cb * P.qd + q];
+      const double mu = hyper(P.q + q), v = hyper(2 * P.q + q);
       double sn, cs;
       sincospi(2.0 * (xi * mu), &sn, &cs);
       fac[(q * 3 + 0) * NB + m] = cs;
@@ -324,12 +381,17 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P) {
       }
     }
     if (side == 0) {
-      const double da = valid ? ((P.noise ? P.noise[ci] : 0.0) + P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0) + P.jitter) : 0.0;
+      const double da = valid ? ((P.noise ? P.noise[ci] : 0.0) + nscal + P.jitter) : 0.0;
       dloc[m] = da;
       if (writer) {
         const int64_t vi = (int64_t)b * P.sVec + i;
         pre[(int64_t)(3 * P.q) * P.np + i] = xi;
-        P.r[vi] = valid ? (P.y[ci] - P.mean[ci]) : 0.0;
+        double mean_i;
+        if (FIT) {
+          mean_i = thl[F.nmean - 1];                             // the constant, or the bias of a linear mean (d = 1: one weight)
+          if (F.nmean > 1) mean_i += xi * thl[0];
+        } else mean_i = valid ? P.mean[ci] : 0.0;
+        P.r[vi] = valid ? (P.y[ci] - mean_i) : 0.0;
         P.diagadd[vi] = da;
       }
     }
@@ -2540,48 +2602,6 @@ __global__ __launch_bounds__(256) void k_pred_in(PgmDev P, const double* __restr
   Ks[(int64_t)gi * Mp + gj] = (gi < P.n && gj < M) ? Kin[(int64_t)gi * ldk + gj] : 0.0;
 }
 
-// ---------------------------------------------------------------------------
-// Device-resident fit (SURVEY.md section 8f row 2): one optimiser iteration of pgmuvi/trainers.py:177-195 --
-// constraint transforms, the evaluation above, the chain rule back to the raw parameters, the SGD / Adam / AdamW
-// update, the loss and parameter log -- is two small kernels around the evaluation's launch sequence, all of it one
-// hipGraph replayed per iteration with no host work in between.  Raw parameter vector (P entries):
-//   [ mean: constant, or d weights + bias (linear) | w (Q) | mu (Q d) | v (Q d) | (learned scalar noise) ].
-// ---------------------------------------------------------------------------
-struct FitDev {
-  int P, n, d, q, qd, nmean, has_noise, optimizer, max_iter;      // nmean: 1 (constant mean) or d+1 (linear); optimizer: 0 SGD, 1 Adam, 2 AdamW
-  const double* x;      // [n][d] (linear mean)
-  double lr, beta1, beta2, eps, weight_decay;
-  double* raw;          // [P] in/out
-  const int* ckind;     // [P] 0 none, 1 softplus + lb, 2 ub - softplus(-raw), 3 lb + span sigmoid(raw)
-  const double* ca;     // [P] lb (kinds 1, 3) or ub (kind 2)
-  const double* cb;     // [P] span (kind 3)
-  double* theta;        // [P] constrained values of this iteration
-  double* mean_vec;     // [n]
-  double* noise_scalar; // [1]
-  double* m1;           // [P] Adam first moment
-  double* m2;           // [P] Adam second moment
-  int* it;              // [1] iterations done so far
-  int* it_host;         // host-mapped copy of it (+ [1]: the evaluation's status, written by the evaluation itself): the host reads the log without a device copy
-  double* loss_hist;    // [max_iter]
-  double* raw_hist;     // [max_iter][P] raw parameters after each step
-  // priors on the constrained parameters (MAP): the reference's ExactMarginalLogLikelihood adds sum log p(theta) before the
-  // division by N (pgmuvi/lightcurve.py:3273-3322 registers Normal and LogNormal priors)
-  const int* pkind;     // [P] 0 none, 1 Normal(loc, scale), 2 LogNormal(loc, scale)
-  const double* ploc;   // [P]
-  const double* pscale; // [P]
-};
-
-__device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }
-__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
-
-__device__ __forceinline__ double fit_theta(const FitDev& F, int p) {
-  const double r = F.raw[p];
-  if (F.ckind[p] == 1) return softplus_d(r) + F.ca[p];
-  if (F.ckind[p] == 2) return F.ca[p] - softplus_d(-r);
-  if (F.ckind[p] == 3) return sigmoid_d(r) * F.cb[p] + F.ca[p];
-  return r;
-}
-
 __global__ __launch_bounds__(256) void k_fit_pre(FitDev F) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   __shared__ double mpar[PGM_MAX_D + 1];
@@ -2732,6 +2752,19 @@ __global__ __launch_bounds__(256) void k_fit_post(FitDev F, const double* __rest
   __shared__ double red[256], sums[PGM_MAX_D + 2];
   const FitLoads L = fit_loads(F);
   fit_post_body<256>(F, L, mll, g_w, g_mu, g_v, g_noise, g_mean, red, sums);
+}
+
+// k_finalize and k_fit_post in one launch (one light curve of at most FIN_THREADS_K = 1024 points: the scalars and the per-point
+// gradients are ONE workgroup's work, and the optimiser step needs nothing from anybody else): the iteration of pgm_fit_* loses a launch.
+__global__ __launch_bounds__(FIN_THREADS_K) void k_finalize_fit(PgmDev P, FitDev F) {
+  __shared__ double red[256], sums[PGM_MAX_D + 2];
+  const FitLoads L = fit_loads(F);
+  finalize_role<FIN_THREADS_K>(P, 0, 0, red);
+  finalize_role<FIN_THREADS_K>(P, 0, 1, red);
+  __syncthreads();                                              // (the results are in the caller's arrays: this workgroup's own stores, complete)
+  const double* mll = (const double*)P.outp[0];
+  fit_post_body<FIN_THREADS_K>(F, L, mll, (const double*)P.outp[1], (const double*)P.outp[2], (const double*)P.outp[3],
+                               (const double*)P.outp[4], (const double*)P.outp[5], red, sums);
 }
 
 // ---------------------------------------------------------------------------
