@@ -122,7 +122,8 @@ int pgm_mll_value_grad_f64(pgm_ws* ws, const double* x, const double* y, const d
  * device array of `batch` values.  All problems advance together, one launch
  * per algorithm step with the batch on gridDim.z.
  *
- * Light curves of at most 128 points (1-D inputs; pgmuvi's one published workload has 89, paper/paper.md:113): the whole
+ * Light curves of at most 128 points (d = 1 or 2; pgmuvi's one published workload has 89, paper/paper.md:113, the multiband
+ * light curve of its Lomb-Scargle notebook 106 in three bands): the whole
  * evaluation -- factors, matrix, factorisation, inverse, gradient contraction, results, status -- is ONE launch, one
  * workgroup per light curve (k_small); no launch graph, nothing but the results and what pgm_predict_f64 reads later is
  * written to memory.  Same results as the launch sequence of every other size (value: the same bits; gradients: 1e-12),
@@ -208,7 +209,7 @@ int64_t pgm_profile_early_inverse_products(const pgm_ws* ws);
  * pgm_fit_run enqueues `iters` more iterations; pgm_fit_read synchronises and returns the iterations done, the loss
  * -mll per iteration, the raw parameters after each step ([iters][P]), the current raw parameters and the last
  * factorisation status (the device writes this log to host-mapped memory as it goes: a read is a stream synchronisation
- * and host copies).  For n <= 128 (d = 1) an iteration is ONE launch -- constraint transforms, the evaluation, the chain
+ * and host copies).  For n <= 128 an iteration is ONE launch -- constraint transforms, the evaluation, the chain
  * rule and the optimiser step inside k_small -- replayed 25 iterations per graph.
  * pgm_fit_set_priors (optional, before the first pgm_fit_run): MAP instead of maximum likelihood -- per raw-vector entry
  * a prior on the CONSTRAINED value, kind 0 none, 1 Normal(loc, scale), 2 LogNormal(loc, scale) (the priors

@@ -2049,6 +2049,8 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
             }
           }
         }
+        // (DPP row reductions here instead of the LDS-crossbar butterfly, wave_sum_dpp: N=4096 1.869 -> 1.863 ms, N=2048 0.552 -> 0.550,
+        //  64 x N=2048 within the noise -- round 6, same-box A/B; not worth other gradient bits)
         gw = wave_sum(gw); gmu = wave_sum(gmu); gv = wave_sum(gv);
         if (wp.lane == 0) { mypart[q] += gw; mypart[Q + q] += gmu; mypart[2 * Q + q] += gv; }
       }
@@ -2768,7 +2770,7 @@ __global__ __launch_bounds__(FIN_THREADS_K) void k_finalize_fit(PgmDev P, FitDev
 }
 
 // ---------------------------------------------------------------------------
-// ONE LAUNCH for a light curve of at most 128 points (round 6; 1-D spectral mixture).  The reference's one published workload is
+// ONE LAUNCH for a light curve of at most 128 points (round 6; spectral mixture, one or two input dimensions).  The reference's one published workload is
 // N = 89 (/root/reference/paper/paper.md:113): a single diagonal block, for which an evaluation used to be k_prebuild -> k_diag ->
 // k_lauum_grad -> k_finalize -- four dependent launches of which only the second does more than a few microseconds of work -- and a
 // training iteration seven (k_fit_pre, k_precompute, k_build, k_diag, k_lauum_grad, k_finalize, k_fit_post).  Here one workgroup of
@@ -2784,25 +2786,31 @@ __global__ __launch_bounds__(FIN_THREADS_K) void k_finalize_fit(PgmDev P, FitDev
 //   F  mll, gradients, status -> the caller's arrays and the workspace;  (FIT) the optimiser step of k_fit_post
 // The batch rides on gridDim.z (any number of short light curves per call, each with its own length: pts()).
 // ---------------------------------------------------------------------------
+template <int D, int ORDER>
 struct LoadFromFactors {
-  const double* fac;    // LDS [(3 q + k) * NB + m]: cos, sin, x v pi sqrt2 per mixture; then raw x
+  const double* fac;    // LDS [(3 qd + k) * NB + m]: cos, sin, x v pi sqrt2 per (mixture, dimension); then raw x per dimension
   const double* wl;     // LDS [Q] mixture weights
   const double* dadd;   // LDS [NB] diagonal addend
   int Q, n;
   __device__ __forceinline__ v4d operator()(const DiagCtx&, int i, int j, int lane) const {
     const int g = lane >> 4, col = j * DB + (lane & 15);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int q = 0; q < Q; ++q) {
-      const double wq = wl[q];
-      const double* cq = fac + q * 3 * NB;
-      const double cc0 = wq * cq[col], cs0 = wq * cq[NB + col], cv0 = cq[2 * NB + col];
+    if constexpr (D == 1) {                                     // (the expressions of build_part_1d)
+      for (int q = 0; q < Q; ++q) {
+        const double wq = wl[q];
+        const double* cq = fac + q * 3 * NB;
+        const double cc0 = wq * cq[col], cs0 = wq * cq[NB + col], cv0 = cq[2 * NB + col];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = i * DB + g + 4 * r;
-        const double rc = cq[m], rs = cq[NB + m], rv = cq[2 * NB + m];
-        const double d0 = rv - cv0;
-        acc[r] = __builtin_fma(exp_neg_fast(-(d0 * d0)), __builtin_fma(rc, cc0, rs * cs0), acc[r]);
+        for (int r = 0; r < 4; ++r) {
+          const int m = i * DB + g + 4 * r;
+          const double rc = cq[m], rs = cq[NB + m], rv = cq[2 * NB + m];
+          const double d0 = rv - cv0;
+          acc[r] = __builtin_fma(exp_neg_fast(-(d0 * d0)), __builtin_fma(rc, cc0, rs * cs0), acc[r]);
+        }
       }
+    } else {                                                    // (k_build<2, ORDER>: sm_pair on the staged factors)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sm_pair<D, ORDER>(fac, fac, wl, Q, i * DB + g + 4 * r, col);
     }
     v4d out;
 #pragma unroll
@@ -2820,20 +2828,20 @@ struct LoadFromFactors {
 constexpr int SMALL_MAXT = 3;                                  // sub-blocks of the upper triangle per wavefront: ceil(36 / 16)
 constexpr int SMALL_VIMG = (NB / DB) * (NB / DB + 1) / 2 * DB * DB;   // 36 sub-blocks of 256
 // doubles of dynamic LDS
-__host__ __device__ constexpr int small_lds_doubles(int q) {
-  return SMALL_VIMG + (3 * q + 1) * NB + DB * DB + 8 * NB + 64 + 64 + 3 * PGM_MAX_QD + 64 + 8 + 16 * (3 * PGM_MAX_QD + 1) + 256 + 8 + 10 * 64;
+__host__ __device__ constexpr int small_lds_doubles(int q, int d = 1) {
+  return SMALL_VIMG + (3 * q * d + d) * NB + DB * DB + 8 * NB + 64 + 64 + 3 * PGM_MAX_QD + 64 + 8 + 16 * (3 * PGM_MAX_QD + 1) + 256 + 8 + 10 * 64;
 }
 
-template <bool FIT>
+template <bool FIT, int D = 1, int ORDER = 0>
 __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NS = NB / DB;
   const int b = blockIdx.z, t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int Q = P.q, nslot = 3 * Q + 1;
+  const int Q = P.q, QD = Q * D, nslot = Q + 2 * QD + 1;
   double* M = sm;                                   // factorisation: prow [2][8][256] | dg [8][256] | sup [8][256]; then the V image [36][256]
-  double* fac = M + SMALL_VIMG;                     // [(3 Q + 1)][NB]
-  double* uiS = fac + (3 * Q + 1) * NB;             // [256]
+  double* fac = M + SMALL_VIMG;                     // [(3 Q D + D)][NB]
+  double* uiS = fac + (3 * QD + D) * NB;            // [256]
   double* rsv = uiS + DB * DB;                      // residual (consumed by the forward substitution)
   double* zsv = rsv + NB;                           // z = V r
   double* alv = zsv + NB;                           // alpha = A^-1 r
@@ -2867,7 +2875,8 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   //  evaluation of a short light curve otherwise.  No barrier of this kernel waits for memory: lds_barrier.)
 
   // (the observation time this thread needs in phase B, requested now: its round trip overlaps that of the parameters)
-  const double x_pre = ((t & (NB - 1)) < n) ? P.x[(int64_t)cb * P.cstride + (t & (NB - 1))] : 0.0;
+  // (dimension (t >> 7) % D of point t & 127: what this thread needs in every round of the factor loop below)
+  const double x_pre = ((t & (NB - 1)) < n) ? P.x[((int64_t)cb * P.cstride + (t & (NB - 1))) * D + ((t >> 7) % D)] : 0.0;
   double y_pre = 0.0, nz_pre = 0.0, mean_pre = 0.0;
   if (t < NB && t < n) {
     const int64_t ci = (int64_t)cb * P.cstride + t;
@@ -2887,12 +2896,12 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     if (t < F.P) { const double th = fit_theta_of(L); thl[t] = th; F.theta[t] = th; if (F.has_noise && t == F.P - 1) F.noise_scalar[0] = th; }
     lds_barrier();
   }
-  if (t < 3 * Q) {
+  if (t < Q + 2 * QD) {                                          // [w (Q) | mu (Q D) | v (Q D)]
     double val;
     if (FIT) val = thl[F.nmean + t];
     else if (t < Q) val = P.w[(int64_t)cb * Q + t];
-    else if (t < 2 * Q) val = P.mu[(int64_t)cb * Q + (t - Q)];
-    else val = P.v[(int64_t)cb * Q + (t - 2 * Q)];
+    else if (t < Q + QD) val = P.mu[(int64_t)cb * QD + (t - Q)];
+    else val = P.v[(int64_t)cb * QD + (t - Q - QD)];
     hypl[t] = val;
     P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = val;
   }
@@ -2901,26 +2910,29 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   // ---- B: per-point factors
   const double nscal = FIT ? (F.has_noise ? thl[F.P - 1] : 0.0)
                            : P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0);
-  for (int e = t; e < NB * Q; e += DIAG_THREADS) {
-    const int m = e & (NB - 1), q = e >> 7;
-    const double xi = x_pre;                                    // (m == t & 127 in every round: DIAG_THREADS is a multiple of NB)
-    const double mu = hypl[Q + q], v = hypl[2 * Q + q];
+  for (int e = t; e < NB * QD; e += DIAG_THREADS) {
+    const int m = e & (NB - 1), qd = e >> 7;                    // qd = q D + dd
+    const double xi = x_pre;                                    // (m == t & 127 and dd == (t >> 7) % D in every round: 8 rows of 128 threads)
+    const double mu = hypl[Q + qd], v = hypl[Q + QD + qd];
     double sn, cs;
     sincospi(2.0 * (xi * mu), &sn, &cs);
     const double xv = xi * v * PI_SQRT2;
-    fac[(q * 3 + 0) * NB + m] = cs; fac[(q * 3 + 1) * NB + m] = sn; fac[(q * 3 + 2) * NB + m] = xv;
-    pre[(int64_t)(q * 3 + 0) * P.np + m] = cs; pre[(int64_t)(q * 3 + 1) * P.np + m] = sn; pre[(int64_t)(q * 3 + 2) * P.np + m] = xv;
+    fac[(qd * 3 + 0) * NB + m] = cs; fac[(qd * 3 + 1) * NB + m] = sn; fac[(qd * 3 + 2) * NB + m] = xv;
+    pre[(int64_t)(qd * 3 + 0) * P.np + m] = cs; pre[(int64_t)(qd * 3 + 1) * P.np + m] = sn; pre[(int64_t)(qd * 3 + 2) * P.np + m] = xv;
   }
   if (t < NB) {
     const int m = t;
     const bool valid = m < n;
-    const double xi = x_pre;
-    fac[3 * Q * NB + m] = xi;
-    pre[(int64_t)(3 * Q) * P.np + m] = xi;
+    double xd[D];
+    xd[0] = x_pre;                                             // (t < 128: dimension 0)
+#pragma unroll
+    for (int dd = 1; dd < D; ++dd) xd[dd] = valid ? P.x[((int64_t)cb * P.cstride + m) * D + dd] : 0.0;
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) { fac[(3 * QD + dd) * NB + m] = xd[dd]; pre[(int64_t)(3 * QD + dd) * P.np + m] = xd[dd]; }
     double mean_i;
     if (FIT) {
-      mean_i = thl[F.nmean - 1];                               // the constant, or the bias of a linear mean (d = 1: one weight)
-      if (F.nmean > 1) mean_i += xi * thl[0];
+      mean_i = thl[F.nmean - 1];                               // the constant, or the bias of a linear mean (its d weights first)
+      if (F.nmean > 1) for (int dd = 0; dd < D; ++dd) mean_i += xd[dd] * thl[dd];
       if (valid) F.mean_vec[m] = mean_i;
     } else mean_i = mean_pre;
     const double rr = valid ? (y_pre - mean_i) : 0.0;
@@ -2939,7 +2951,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
   //  Measured and not kept: the chain factoring sub-block (0, 0) beside the build instead of behind it -- the build's wavefronts on
   //  the chain's SIMD slow that factorisation down by more than it gains: N=89 75.0k against 74.3k clock ticks, N=128, Q=4 131.3k / 128.7k.)
   {
-    const LoadFromFactors build{fac, hypl, dadd, Q, n};
+    const LoadFromFactors<D, ORDER> build{fac, hypl, dadd, Q, n};
     const int T = nse * (nse + 1) / 2;
     for (int u = wave; u < T; u += 16) {
       int i, j;
@@ -3102,34 +3114,109 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
         G[k][r] = (m < n && col < n) ? wt * (alv[m] * alv[col] - G[k][r]) : 0.0;
       }
     }
-    const double* xs = fac + 3 * Q * NB;
+    const double* xs = fac + 3 * QD * NB;                       // raw x per dimension
     double* mypart = wpart + wave * nslot;
+    if constexpr (D == 1) {
 #pragma unroll 1
-    for (int q = 0; q < Q; ++q) {
-      const double* rq = fac + q * 3 * NB;
-      double gw = 0.0, gmu = 0.0, gv = 0.0;
+      for (int q = 0; q < Q; ++q) {
+        const double* rq = fac + q * 3 * NB;
+        double gw = 0.0, gmu = 0.0, gv = 0.0;
 #pragma unroll
-      for (int k = 0; k < SMALL_MAXT; ++k) {
-        if (k >= nt || tj[k] >= nse) continue;
-        const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
-        const double cc_ = rq[col], cs_ = rq[NB + col], cv = rq[2 * NB + col], cx = xs[col];
+        for (int k = 0; k < SMALL_MAXT; ++k) {
+          if (k >= nt || tj[k] >= nse) continue;
+          const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
+          const double cc_ = rq[col], cs_ = rq[NB + col], cv = rq[2 * NB + col], cx = xs[col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = ti[k] * DB + g + 4 * r;
-          const double rc = rq[m], rs = rq[NB + m], rv = rq[2 * NB + m], rx = xs[m];
-          const double ds = rv - cv;
-          const double GE = G[k][r] * exp_neg_fast(-(ds * ds));
-          const double CC = __builtin_fma(rc, cc_, rs * cs_);
-          const double SN = __builtin_fma(rs, cc_, -(rc * cs_));
-          const double tau = rx - cx;
-          const double tt = GE * tau;
-          gw = __builtin_fma(GE, CC, gw);
-          gmu = __builtin_fma(tt, SN, gmu);
-          gv = __builtin_fma(tt, CC * tau, gv);
+          for (int r = 0; r < 4; ++r) {
+            const int m = ti[k] * DB + g + 4 * r;
+            const double rc = rq[m], rs = rq[NB + m], rv = rq[2 * NB + m], rx = xs[m];
+            const double ds = rv - cv;
+            const double GE = G[k][r] * exp_neg_fast(-(ds * ds));
+            const double CC = __builtin_fma(rc, cc_, rs * cs_);
+            const double SN = __builtin_fma(rs, cc_, -(rc * cs_));
+            const double tau = rx - cx;
+            const double tt = GE * tau;
+            gw = __builtin_fma(GE, CC, gw);
+            gmu = __builtin_fma(tt, SN, gmu);
+            gv = __builtin_fma(tt, CC * tau, gv);
+          }
+        }
+        gw = wave_sum_dpp(gw); gmu = wave_sum_dpp(gmu); gv = wave_sum_dpp(gv);
+        if (lane == 0) { mypart[q] = gw; mypart[Q + q] = gmu; mypart[2 * Q + q] = gv; }
+      }
+    } else {
+      // two input dimensions (the general loop of lauum_grad_item on 16 x 16 sub-blocks): K = prod_d sum_q (ORDER 0) or sum_q prod_d
+      auto pair_terms = [&](int qd, int m, int col, int dd, double& E, double& CC, double& SN, double& TAU) {
+        const double* rq = fac + qd * 3 * NB;
+        const double rc = rq[m], rsn = rq[NB + m], cc_ = rq[col], cs_ = rq[NB + col];
+        const double ds = rq[2 * NB + m] - rq[2 * NB + col];
+        E = exp_neg(-(ds * ds));
+        CC = rc * cc_ + rsn * cs_;
+        SN = rsn * cc_ - rc * cs_;
+        TAU = xs[dd * NB + m] - xs[dd * NB + col];
+      };
+      double Sd[SMALL_MAXT][D][4];                               // ORDER 0: sum_q w_q E CC per dimension and pair
+      if (ORDER == 0) {
+#pragma unroll
+        for (int k = 0; k < SMALL_MAXT; ++k)
+#pragma unroll
+          for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Sd[k][dd][r] = 0.0;
+#pragma unroll 1
+        for (int q = 0; q < Q; ++q) {
+#pragma unroll
+          for (int k = 0; k < SMALL_MAXT; ++k) {
+            if (k >= nt || tj[k] >= nse) continue;
+            const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                double E, CC, SN, TAU;
+                pair_terms(q * D + dd, ti[k] * DB + g + 4 * r, col, dd, E, CC, SN, TAU);
+                Sd[k][dd][r] += hypl[q] * E * CC;
+              }
+          }
         }
       }
-      gw = wave_sum_dpp(gw); gmu = wave_sum_dpp(gmu); gv = wave_sum_dpp(gv);
-      if (lane == 0) { mypart[q] = gw; mypart[Q + q] = gmu; mypart[2 * Q + q] = gv; }
+#pragma unroll 1
+      for (int q = 0; q < Q; ++q) {
+        double gw = 0.0, gmu[D], gv[D];
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) { gmu[dd] = 0.0; gv[dd] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < SMALL_MAXT; ++k) {
+          if (k >= nt || tj[k] >= nse) continue;
+          const int g = lane >> 4, col = tj[k] * DB + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = ti[k] * DB + g + 4 * r;
+            double E[D], CC[D], SN[D], TAU[D];
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) pair_terms(q * D + dd, m, col, dd, E[dd], CC[dd], SN[dd], TAU[dd]);
+            const double Gv = G[k][r];
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+              const int o = 1 - dd;
+              const double oth = (ORDER == 0) ? Sd[k][o][r] : E[o] * CC[o];
+              const double GE = Gv * oth * E[dd];
+              if (ORDER == 0) gw += GE * CC[dd];
+              gmu[dd] += GE * SN[dd] * TAU[dd];
+              gv[dd] += GE * CC[dd] * TAU[dd] * TAU[dd];
+            }
+            if (ORDER != 0) gw += Gv * E[0] * CC[0] * E[1] * CC[1];
+          }
+        }
+        gw = wave_sum_dpp(gw);
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) { gmu[dd] = wave_sum_dpp(gmu[dd]); gv[dd] = wave_sum_dpp(gv[dd]); }
+        if (lane == 0) {
+          mypart[q] = gw;
+#pragma unroll
+          for (int dd = 0; dd < D; ++dd) { mypart[Q + q * D + dd] = gmu[dd]; mypart[Q + QD + q * D + dd] = gv[dd]; }
+        }
+      }
     }
   }
   SSTAMP();
@@ -3154,20 +3241,20 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     }
   }
   if (P.need_grad) {
-    if (t >= 64 && t < 64 + 3 * Q) {                            // slot s of the hyper-parameter gradients: w (Q), mu (Q), v (Q)
+    if (t >= 64 && t < 64 + Q + 2 * QD) {                        // slot s of the hyper-parameter gradients: w (Q), mu (Q D), v (Q D)
       const int s3 = t - 64;
       double acc = 0.0;
       for (int wv = 0; wv < 16; ++wv) acc += wpart[wv * nslot + s3];     // fixed order
       double val;
       if (s3 < Q) val = half_n * acc;
-      else if (s3 < 2 * Q) val = half_n * (-2.0 * PI) * hypl[s3 - Q] * acc;
-      else val = half_n * (-2.0 * TWO_PI_SQ) * hypl[s3] * hypl[s3 - 2 * Q] * acc;
+      else if (s3 < Q + QD) val = half_n * (-2.0 * PI) * hypl[(s3 - Q) / D] * acc;
+      else val = half_n * (-2.0 * TWO_PI_SQ) * hypl[s3] * hypl[(s3 - Q - QD) / D] * acc;
       if (bad) val = qnan;
       outs[1 + s3] = val;
       P.out_small[b * P.sOut + 1 + s3] = val;
       if (s3 < Q) { if (P.g_w) P.g_w[(int64_t)cb * Q + s3] = val; }
-      else if (s3 < 2 * Q) { if (P.g_mu) P.g_mu[(int64_t)cb * Q + (s3 - Q)] = val; }
-      else { if (P.g_v) P.g_v[(int64_t)cb * Q + (s3 - 2 * Q)] = val; }
+      else if (s3 < Q + QD) { if (P.g_mu) P.g_mu[(int64_t)cb * QD + (s3 - Q)] = val; }
+      else { if (P.g_v) P.g_v[(int64_t)cb * QD + (s3 - Q - QD)] = val; }
     }
     if (t >= 128 && t < 128 + NB) {
       const int m = t - 128;
@@ -3188,7 +3275,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     const int tl = t & 63;                                      // (P <= 51 parameters: wavefront 0 holds them; the others only need `it`)
     L.raw = fitl[0 * 64 + tl]; L.ca = fitl[1 * 64 + tl]; L.cb = fitl[2 * 64 + tl]; L.ploc = fitl[3 * 64 + tl]; L.pscale = fitl[4 * 64 + tl];
     L.m1 = fitl[5 * 64 + tl]; L.m2 = fitl[6 * 64 + tl]; L.ckind = (int)fitl[7 * 64 + tl]; L.pkind = (int)fitl[8 * 64 + tl]; L.it = (int)fitl[9 * 64 + tl];
-    fit_post_body<DIAG_THREADS>(F, L, outs, outs + 1, outs + 1 + Q, outs + 1 + 2 * Q, gno, gme, red, sums);
+    fit_post_body<DIAG_THREADS>(F, L, outs, outs + 1, outs + 1 + Q, outs + 1 + Q + QD, gno, gme, red, sums);
   }
   SSTAMP();
 #ifdef PGM_SMALL_STAMPS
