@@ -401,13 +401,15 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
 }
 
 
-template <int D, int ORDER, int SPLIT1 = BUILD_SPLIT_1D>
+template <int D, int ORDER, int SPLIT1 = (D == 1 ? BUILD_SPLIT_1D : 1)>
 __global__ __launch_bounds__(256) void k_build(PgmDev P) {
   const int b = blockIdx.z;
   int ib, jb;
   // (1-D: a workgroup builds a quarter of a tile, 32 rows: 2112 workgroups even out over the 256 CUs where 528 did not;
-  //  a sixteenth, 8 rows, when the whole call has only a few tiles -- short light curves: 9 -> 5 us at N=128)
-  constexpr int SPLIT = (D == 1) ? SPLIT1 : 1;
+  //  a sixteenth, 8 rows, when the whole call has only a few tiles -- short light curves: 9 -> 5 us at N=128.
+  //  2-D: whole tiles, or sixteenths when the call has few tiles -- the reference's 2-D examples have 225 and 250 points, three
+  //  tiles: one workgroup per tile took 48 of the evaluation's 152 us, round 6)
+  constexpr int SPLIT = SPLIT1;
   const int part = blockIdx.x % SPLIT;
   if (P.build_beside) { ib = 0; jb = blockIdx.x / SPLIT; }      // block row 0 only: the rest is built beside diagonal block 0 (k_diag)
   else tri_decode(blockIdx.x / SPLIT, ib, jb);
@@ -427,7 +429,8 @@ __global__ __launch_bounds__(256) void k_build(PgmDev P) {
     return;
   }
   const int n = pts(P, b);
-  for (int rr = 0; rr < NB / 4; ++rr) {
+  constexpr int RR = NB / 4 / SPLIT;                             // rows per thread
+  for (int rr = part * RR; rr < (part + 1) * RR; ++rr) {
     const int m = rg + 4 * rr;
     const int gi = ib * NB + m;
     v2d out;
