@@ -313,7 +313,7 @@ __device__ __forceinline__ double fit_theta(const FitDev& F, int p) {
   return r;
 }
 
-// Short light curves (one of at most 55 tiles, 1-D): per-point factors and kernel matrix in ONE launch in front of the graph --
+// Short light curves (one of at most 55 tiles; round 6: also with two input dimensions): per-point factors and kernel matrix in ONE launch in front of the graph --
 // an evaluation of N = 89 points is five dependent launches of which the first two do microseconds of work.  A workgroup
 // computes the factors of its tile's 128 rows and 128 columns itself, straight from the caller's arrays into LDS (4 sincospi per
 // thread at Q = 4) and builds its sixteenth of the tile from them (build_part_1d, the code of k_build); the workgroups of the
@@ -322,7 +322,7 @@ __device__ __forceinline__ double fit_theta(const FitDev& F, int p) {
 // FIT (pgm_fit_*: the device-resident optimiser loop): the constrained parameters come from the raw vector -- every workgroup
 // transforms the (at most 51) parameters for itself, workgroup 0 leaves them in F.theta for the step at the end of the iteration --
 // and the mean is the constant (or linear) mean module's: k_fit_pre, k_precompute and k_build in one launch.
-template <bool FIT>
+template <bool FIT, int D = 1, int ORDER = 0>
 __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
   constexpr int SPLIT = BUILD_SPLIT_SMALL;
   const int b = blockIdx.z, t = threadIdx.x;
@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
   double* dloc = wl + PGM_MAX_QD;
   double* thl = dloc + NB;                                      // [64] (FIT) constrained parameters
   const int cb = caller_slot(P, b), n = pts(P, b);
+  const int Q = P.q, QD = Q * D;
   if (blockIdx.x == 0 && t == 0) P.info[b] = 0;
   publish_output_pointers(P);
   if (FIT) {
@@ -346,16 +347,16 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
     }
     __syncthreads();
   }
-  // parameter s of [w (q) | mu (q) | v (q)] (d = 1)
+  // parameter s of [w (Q) | mu (Q D) | v (Q D)]
   auto hyper = [&](int s3) -> double {
     if (FIT) return thl[F.nmean + s3];
-    if (s3 < P.q) return P.w[(int64_t)cb * P.q + s3];
-    if (s3 < 2 * P.q) return P.mu[(int64_t)cb * P.qd + (s3 - P.q)];
-    return P.v[(int64_t)cb * P.qd + (s3 - 2 * P.q)];
+    if (s3 < Q) return P.w[(int64_t)cb * Q + s3];
+    if (s3 < Q + QD) return P.mu[(int64_t)cb * QD + (s3 - Q)];
+    return P.v[(int64_t)cb * QD + (s3 - Q - QD)];
   };
   const double nscal = FIT ? (F.has_noise ? thl[F.P - 1] : 0.0) : P.noise_scalar + (P.noise_scalar_dev ? P.noise_scalar_dev[cb] : 0.0);
-  if (blockIdx.x == 0 && t < P.q + 2 * P.qd) P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = hyper(t);
-  if (t < P.q) wl[t] = hyper(t);
+  if (blockIdx.x == 0 && t < Q + 2 * QD) P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + t] = hyper(t);
+  if (t < Q) wl[t] = hyper(t);
   const bool writer = (ib == jb) && part == 0;                  // (uniform) this workgroup leaves block row ib's per-point values behind
   double* pre = P.pre + b * P.sPre;
   // points of the row block (side 0) and of the column block (side 1): one (point, side) per thread and round
@@ -364,20 +365,25 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
     const int i = (side ? jb : ib) * NB + m;
     const bool valid = i < n;
     const int64_t ci = (int64_t)cb * P.cstride + i;
-    const double xi = valid ? P.x[ci] : 0.0;
     double* fac = side ? cold : rowd;
-    fac[3 * P.q * NB + m] = xi;
-    for (int q = 0; q < P.q; ++q) {
-      const double mu = hyper(P.q + q), v = hyper(2 * P.q + q);
+    double xd[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      xd[dd] = valid ? P.x[ci * D + dd] : 0.0;
+      fac[(3 * QD + dd) * NB + m] = xd[dd];
+    }
+    for (int qd = 0; qd < QD; ++qd) {
+      const double xi = xd[D == 1 ? 0 : qd % D];
+      const double mu = hyper(Q + qd), v = hyper(Q + QD + qd);
       double sn, cs;
       sincospi(2.0 * (xi * mu), &sn, &cs);
-      fac[(q * 3 + 0) * NB + m] = cs;
-      fac[(q * 3 + 1) * NB + m] = sn;
-      fac[(q * 3 + 2) * NB + m] = xi * v * PI_SQRT2;
+      fac[(qd * 3 + 0) * NB + m] = cs;
+      fac[(qd * 3 + 1) * NB + m] = sn;
+      fac[(qd * 3 + 2) * NB + m] = xi * v * PI_SQRT2;
       if (writer && side == 0) {
-        pre[(int64_t)(q * 3 + 0) * P.np + i] = cs;
-        pre[(int64_t)(q * 3 + 1) * P.np + i] = sn;
-        pre[(int64_t)(q * 3 + 2) * P.np + i] = xi * v * PI_SQRT2;
+        pre[(int64_t)(qd * 3 + 0) * P.np + i] = cs;
+        pre[(int64_t)(qd * 3 + 1) * P.np + i] = sn;
+        pre[(int64_t)(qd * 3 + 2) * P.np + i] = xi * v * PI_SQRT2;
       }
     }
     if (side == 0) {
@@ -385,11 +391,12 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
       dloc[m] = da;
       if (writer) {
         const int64_t vi = (int64_t)b * P.sVec + i;
-        pre[(int64_t)(3 * P.q) * P.np + i] = xi;
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) pre[(int64_t)(3 * QD + dd) * P.np + i] = xd[dd];
         double mean_i;
         if (FIT) {
-          mean_i = thl[F.nmean - 1];                             // the constant, or the bias of a linear mean (d = 1: one weight)
-          if (F.nmean > 1) mean_i += xi * thl[0];
+          mean_i = thl[F.nmean - 1];                             // the constant, or the bias of a linear mean (its d weights first)
+          if (F.nmean > 1) for (int dd = 0; dd < D; ++dd) mean_i += xd[dd] * thl[dd];
         } else mean_i = valid ? P.mean[ci] : 0.0;
         P.r[vi] = valid ? (P.y[ci] - mean_i) : 0.0;
         P.diagadd[vi] = da;
@@ -397,7 +404,31 @@ __global__ __launch_bounds__(256) void k_prebuild(PgmDev P, FitDev F) {
     }
   }
   __syncthreads();
-  build_part_1d<SPLIT>(P, rowd, cold, wl, b, ib, jb, part, t, dloc);
+  if constexpr (D == 1) {
+    build_part_1d<SPLIT>(P, rowd, cold, wl, b, ib, jb, part, t, dloc);
+  } else {                                                      // (k_build<2, ORDER>'s loop on this workgroup's sixteenth of the tile)
+    double* A = P.A + b * P.sA;
+    const int c2 = (t & 63) * 2, rg = t >> 6;
+    constexpr int RR = NB / 4 / SPLIT;
+    for (int rr = part * RR; rr < (part + 1) * RR; ++rr) {
+      const int m = rg + 4 * rr;
+      const int gi = ib * NB + m;
+      v2d out;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int nloc = c2 + u, gj = jb * NB + nloc;
+        double val;
+        if (gi < n && gj < n) {
+          val = sm_pair<D, ORDER>(rowd, cold, wl, Q, m, nloc);
+          if (gi == gj) val += dloc[m];
+        } else {
+          val = (gi == gj) ? 1.0 : 0.0;
+        }
+        out[u] = val;
+      }
+      *reinterpret_cast<v2d*>(A + (int64_t)gi * P.ld + jb * NB + c2) = out;
+    }
+  }
 }
 
 
