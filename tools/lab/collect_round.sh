@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/lab/collect_round.sh r06: after `gpurun -- bash tools/lab/round_evidence.sh r06` -- copies this run's evidence into profiles/ and drops
+# anything that was not measured on the library that is in the tree now (older profile directories linger in gpurun_out/).
+r=${1:-r06}
+bash tools/lab/collect_profiles.sh $r > /dev/null 2>&1
+for d in gpurun_out/prof_*/; do tag=$(basename $d | sed 's/^prof_//'); if [ -z "$(find $d -maxdepth 1 -newer pgmuvi_amd/libpgmuvi_hip.so -name 'kernel_stats.csv' | head -1)" ]; then rm -f profiles/${r}_*_${tag}.csv profiles/${r}_*_${tag}.json profiles/${r}_*_${tag}.txt; fi; done
+rm -f profiles/${r}_kernel_stats_small.csv profiles/${r}_pmc_hbm_traffic_ragged512.json profiles/${r}_pmc_mfma_util_ragged512.json
+cp gpurun_out/prof_small/kernel_stats.csv profiles/${r}_kernel_stats_small_path.csv
+cp gpurun_out/prof_small_n89/traffic.json profiles/${r}_pmc_hbm_traffic_small_n89.json
+cp gpurun_out/prof_small_n89/mfma_util.json profiles/${r}_pmc_mfma_util_small_n89.json
+cp gpurun_out/prof_small_n89/kernel_stats.csv profiles/${r}_kernel_stats_small_n89.csv
+for f in soak fuzz_parity fuzz_ragged; do grep -v amdgpu.ids gpurun_out/$f.txt > profiles/${r}_$f.txt; done
+[ -f gpurun_out/fitrate.txt ] && grep "^n=" gpurun_out/fitrate.txt > profiles/${r}_fitrate.txt
+[ -f gpurun_out/evalloop_2d.txt ] && cp gpurun_out/evalloop_2d.txt profiles/${r}_evalloop_2d.txt
+ls profiles | grep -c ${r}_; grep -h "_lib_sha16" profiles/${r}_pmc_hbm_traffic_*.json | sort | uniq -c; sha256sum pgmuvi_amd/libpgmuvi_hip.so | cut -c1-16
