@@ -45,7 +45,7 @@ struct TileCfg {
   // issues only 16 MFMAs (~0.4 us) per chunk, less than one L2/Infinity-Cache round trip, so a single
   // prefetched chunk leaves the loop latency-bound; PF > 1 hides it
   static constexpr int PF = PF_;
-  static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8, "prefetch depth must divide the chunks per k-block");
+  static_assert(PF == 1 || PF == 2 || PF == 4 || PF == 8 || PF == 16 || PF == 32, "prefetch depth must divide the chunks per k-block");
   static_assert(DIRECT_ ? (NB / 4) % PF_ == 0 : ((NB / KB_) % PF_ == 0 && KB_ % 4 == 0), "chunking");
   static constexpr int TM = WM / 16, TN = WN / 16;
   static constexpr int WAVES_N = BN / WN;
@@ -144,7 +144,7 @@ template <class C, class PtrFn>
 __device__ __forceinline__ void gemm_direct(int nkb, PtrFn&& ptrs, v4d (&acc)[C::TM][C::TN], bool negate_late, int skip_ks = 0) {
   const WavePos wp = wave_pos<C>();
   constexpr int PD = C::PF, TM = C::TM, TN = C::TN, KS = NB / 4;      // k-steps per k-block
-  static_assert(KS % PD == 0 && PD < KS, "prefetch distance");
+  static_assert(KS % PD == 0 && PD <= KS, "prefetch distance");
   const int g = wp.lane >> 4, i = wp.lane & 15;
   const int ca = (wp.m0 + TM * i) * 8, cb = (wp.n0 + TN * i) * 8;
   auto block = [&](int kb) {

@@ -91,7 +91,7 @@ struct PgmDev {
                       //    pass over V is skipped
   int prebuilt;       // 1: the kernel matrix was built in front of the graph, by k_prebuild together with the per-point factors (short light curves)
   int build_beside;   // 1: k_build builds block row 0 only, the rest of the matrix is built by the spare workgroups of diagonal block 0's launch
-  int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups)
+  int lauum_sub;      // 1: the inverse/gradient launch runs four quarter-tile workgroups per work item (nitems counts workgroups); 2: sixteen sixteenth-tile ones
   int small_eval;     // 1: k_small evaluated this call (the inverse images' identity padding is completed on demand: k_small_pad)
   int generic;        // 1: the kernel is `prog` (q = its parameter count, qd = 0, theta travels through `w` / `hyp`)
   KProg prog;
@@ -147,6 +147,7 @@ struct pgm_ws {
   // early inverse pass (fused sweep, one light curve): the late diagonal-block launches have fewer update tiles than
   // CUs; their spare workgroups form  R_ij = sum_p V_pi^T V_pj  over block rows p that are already final
   int lauum_sub_max;     // inverse/gradient pass: quarter-tile workgroups when a call has at most this many work items in all (0: never)
+  int lauum_sub16_max;   // ... sixteenth-tile workgroups when it has at most this many (0: never)
   int early;             // 0 = off
   int early_t;           // early inverse-pass tasks also in the row-solve launches' idle CUs: most per launch (PGM_EARLY_T, 0: off)
   int early_nb;          // block rows the tables below were made for (-1: none)

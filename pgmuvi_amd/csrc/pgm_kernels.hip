@@ -1853,6 +1853,15 @@ using CfgBigLds = TileCfg<128, 128, 64, 64, 2>;
 struct CfgBig : TileCfg<128, 128, 64, 64, 4, 256, KB, true> { static constexpr int LDS_DOUBLES = CfgBigLds::LDS_DOUBLES; };
 using CfgUpd = CfgBig;                                       // (8 wavefronts per 128x128 tile: measured in round 2, -0.7 %, not kept)
 using CfgSub = CfgSmall;                                     // quarter tiles of the inverse/gradient pass of short light curves
+// Sixteenth tiles (round 6) for light curves of a few block rows, where the launch is a handful of work items on an otherwise
+// idle chip and its length is set by latencies, not by arithmetic (N=256, quarter tiles, ticks of the longest item: multiply
+// 14.5 us -- 64 k-steps with 8 in flight, a memory round trip per 8 --, staging 2.8, epilogue 6.8 of the launch's 25): a 32x32
+// sub-tile per workgroup, one 16x16 MFMA tile per wavefront with PGM_SUB16_PF k-steps in flight (two 8-byte fragments each),
+// 4 pairs per lane in the epilogue.
+#ifndef PGM_SUB16_PF
+#define PGM_SUB16_PF 16
+#endif
+using CfgSub16 = TileCfg<32, 32, 16, 16, PGM_SUB16_PF, 256, KB, true>;
 // The epilogue reuses the GEMM's LDS: per-point factors of the tile's rows and columns for
 // a chunk of mixtures at a time (all of them when Q*d is small, the usual case).
 constexpr int EPI_FIXED = 2 * NB + PGM_MAX_QD + 4 * (3 * PGM_MAX_QD + 1);          // alpha slices, weights, wave partials
@@ -1918,8 +1927,15 @@ __global__ __launch_bounds__(256) void k_ainv_diag(PgmDev P) {
 template <int D, int ORDER, class C>
 __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, int b, int bx, int rows = -1) {
   constexpr int SUB = NB / C::BM;                              // sub-tiles per side (1 or 2)
-  static_assert(C::BM == C::BN && C::NT == NTHREADS && (SUB == 1 || SUB == 2), "whole tiles or quarter tiles");
+  static_assert(C::BM == C::BN && C::NT == NTHREADS && (SUB == 1 || SUB == 2 || SUB == 4), "whole, quarter or sixteenth tiles");
   if (P.info[b] != 0) return;
+#ifdef PGM_LAUUM_STAMPS       // (lab build: clock ticks of the phases of the launch's first work items, printed by their thread 0)
+  long long lst_[8]; int lsn_ = 0;
+#define LSTAMP() do { if (lsn_ < 8) lst_[lsn_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LSTAMP() do {} while (0)
+#endif
+  LSTAMP();
   // the diag(A^-1) items ride at the end of the grid (placed first they delay the long inverse tiles: +0.04 ms)
   if (bx >= P.nitems) { const int a = bx - P.nitems; ainv_diag_item(P, a % P.nb, a / P.nb, lds, b); return; }
   // work item = (tile i <= j, k-blocks [p0, p0+len)): long inverse tiles are split along k so
@@ -1989,6 +2005,7 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
     full_tile();
   }
 
+  LSTAMP();
   if constexpr (SUB == 1) { if (P.ainv_from_tiles && i == j) ainv_diag_from_tile<C>(P, b, j, p0, acc, wp); }
   // ---- epilogue: LDS is free again (gemm_tn ends on a barrier)
   const int Q = P.q;
@@ -2019,6 +2036,7 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
   if (threadIdx.x < Q) wl[threadIdx.x] = P.hyp[(int64_t)b * (PGM_MAX_QD * 3) + threadIdx.x];
   for (int e = threadIdx.x; e < 4 * P.nslot; e += NTHREADS) wpart[e] = 0.0;
   if (nchunks == 1) stage(0, Q); else __syncthreads();
+  LSTAMP();
 
   const double sym = (i == j) ? 1.0 : 2.0;
   const int npts = pts(P, b);
@@ -2038,6 +2056,7 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
         const double wt = shape == SH_FULL ? sym : (tj < shape_tj_lo(shape, ti) ? 0.0 : (shape == SH_UPPER && ti == tj) ? 1.0 : 2.0);
         acc[ti][tj][r] = (valid && wt != 0.0) ? wt * (aa - acc[ti][tj][r]) : 0.0;
       }
+  LSTAMP();
   // One input dimension, every mixture staged at once (the usual case): mixtures outermost and the whole sub-tile unrolled
   // inside -- accumulator elements are addressed statically (no copy of a row of G per step), the three sums are reduced
   // across the wavefront once per mixture instead of once per mixture and MFMA-tile row, the time difference and the row's
@@ -2195,10 +2214,18 @@ __device__ __forceinline__ void lauum_grad_item(const PgmDev& P, double* lds, in
       }
     }
   }
+  LSTAMP();
   __syncthreads();
   double* part = P.partials + b * P.sPart + (int64_t)lb * P.nslot;
   for (int s = threadIdx.x; s < P.nslot; s += NTHREADS)
     part[s] = wpart[s] + wpart[P.nslot + s] + wpart[2 * P.nslot + s] + wpart[3 * P.nslot + s];
+#ifdef PGM_LAUUM_STAMPS
+  LSTAMP();
+  if (threadIdx.x == 0 && b == 0 && (lb < 12 || lb == P.nitems - 1))
+    printf("lauum item %d (i=%d j=%d p0=%d plen=%d cont=%d) ticks: multiply %d stage %d G %d epilogue %d all waves %d  start %lld\n", lb, i, j, p0, plen, (int)cont,
+           (int)(lst_[1] - lst_[0]), (int)(lst_[2] - lst_[0]), (int)(lst_[3] - lst_[0]), (int)(lst_[4] - lst_[0]), (int)(lst_[5] - lst_[0]), lst_[0]);
+#endif
+#undef LSTAMP
 }
 
 // ---------------------------------------------------------------------------

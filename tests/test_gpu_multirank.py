@@ -89,6 +89,38 @@ def test_two_ranks_on_one_gpu_equal_one_process_bit_for_bit(dev, tmp_path):
     assert owners == set(range(rag[0]))
 
 
+def test_chains_over_two_ranks_on_one_gpu_equal_one_process(dev, tmp_path):
+    """Config 5's layout on the hardware a one-GPU box has: four chains, each on its own light curve, dealt two and two over the
+    ranks of one job; each rank drives its chains through the native potential (``pgm_pot_*``) and ONE gather of the draws
+    closes the run.  Both ranks end up with all four chains, and they are the chains this process samples alone: the same
+    trees (leapfrog counts), the same draws (a chain's numbers depend on its id, not on where it ran or with whom)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _gpu_rank_worker as wk
+    from pgmuvi_amd import mcmc
+    C, n = 4, 300
+    buf, err = io.StringIO(), open(tmp_path / "stderr.txt", "w+")
+    rc = launch.spawn_ranks([sys.executable, WORKER, "--gpus", "2", "--chains", str(C), str(n), "--outdir", str(tmp_path)], 2,
+                            visible_devices=launch.visible_gpu_count(), share_gpu=True, out=buf, err=err)
+    err.seek(0)
+    assert rc == 0, err.read()[-4000:]
+    line = json.loads([ln for ln in buf.getvalue().splitlines() if ln.startswith("{")][-1])
+    assert line["world"] == 2 and line["backend"] == "gloo" and line["chains"] == C
+    assert len({r[1] for r in line["ranks"]} | {os.getpid()}) == 3
+    x, y, nz, kw = wk.chain_problem(C, n)
+    one = mcmc.run_mcmc(x.to(dev), y.to(dev), nz.to(dev), **kw)
+    for r in range(2):
+        got = torch.load(tmp_path / f"chains_rank{r}.pt", weights_only=False)
+        assert np.array_equal(got["n_leapfrog"], one["_diagnostics"]["n_leapfrog"])
+        assert got["covar_module.mixture_means_prior"].shape == (C, 5, 2, 1, 1)
+        for k in ("covar_module.mixture_means_prior", "covar_module.mixture_weights_prior", "covar_module.mixture_scales_prior",
+                  "mean_module.mean_prior"):
+            assert np.allclose(got[k], one[k], rtol=1e-9, atol=0), k
+        assert np.allclose(got["potential_energy"], one["_diagnostics"]["potential_energy"], rtol=1e-10, atol=1e-9)
+        assert np.array_equal(got["step_size"], one["_diagnostics"]["step_size"]) or \
+            np.allclose(got["step_size"], one["_diagnostics"]["step_size"], rtol=1e-9)
+
+
 def test_bench_two_ranks_share_the_gpu(dev):
     """``python bench.py --gpus 2 --share-gpu`` as typed: strong scaling (16 x N=512 over two ranks) and the weak headline form;
     rank 0's line comes back through the parent, timing is the MAX over both ranks, the batch is split 8 + 8."""

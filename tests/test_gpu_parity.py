@@ -151,11 +151,13 @@ def test_batched_equals_singles_and_oracle(dev):
     out = evaluate_batch(st(xs), st(ys), st(means), st(ns), st(ws), st(mus), st(vs))
     out2 = evaluate_batch(st(xs), st(ys), st(means), st(ns), st(ws), st(mus), st(vs), chunk=2)
     torch.cuda.synchronize()
-    assert torch.equal(out["mll"], out2["mll"]) and torch.equal(out["g_mu"], out2["g_mu"])
+    # (the value does not depend on how many light curves share the call; the gradient sums do, in their rounding: a call with
+    #  a handful of work items forms them per sixteenth tile and k-block, one with five light curves per quarter tile)
+    assert torch.equal(out["mll"], out2["mll"]) and _rel(out["g_mu"].reshape(-1), out2["g_mu"].reshape(-1)) < 1e-10
     for i in range(B):
         single = _hip_eval(dev, xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
         assert float(single["mll"]) == float(out["mll"][i])          # bitwise: same kernels, batch on gridDim.z
-        assert torch.equal(single["g_w"], out["g_w"][i])
+        assert _rel(single["g_w"], out["g_w"][i]) < 1e-10
         val, gr = orc.mll_value_grad_closed_form(xs[i], ys[i], means[i], ns[i], ws[i], mus[i], vs[i])
         assert abs(float(val) - float(out["mll"][i])) < MLL_TOL
         assert _rel(out["g_v"][i].reshape(-1), gr["v"].reshape(-1)) < GRAD_RTOL

@@ -6,7 +6,6 @@
 * chains sharded over two ``gloo`` ranks == the same chains in one process.
 """
 import os
-import socket
 import sys
 
 import numpy as np
@@ -146,11 +145,9 @@ def test_short_nuts_run_on_a_small_light_curve_finds_the_period():
     assert flat["covar_module.mixture_weights_prior"].shape == (10, 1)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, rendezvous, q):
     import _oracle_backend as ob
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + rendezvous, rank=rank, world_size=world)
     x, y, nz = _lightcurves(3, 32)
     out = mcmc.run_mcmc(x, y, nz, num_mixtures=1, num_samples=6, warmup_steps=6, seed=11, compute=ob.mll_value_grad,
                         group_by_chain=True, max_tree_depth=3, initial_values=_INIT)
@@ -164,16 +161,14 @@ _INIT = {"mean_module.mean_prior": np.array(0.0), "covar_module.mixture_weights_
          "covar_module.mixture_scales_prior": np.array([1 / 1500.0]).reshape(1, 1, 1)}
 
 
-def test_chains_sharded_over_two_gloo_ranks_equal_one_process():
+def test_chains_sharded_over_two_gloo_ranks_equal_one_process(tmp_path):
     """Config 5's layout: each chain has its own light curve, chains are block-partitioned over the ranks, one
     all_gather of the draws at the end; a chain's draws do not depend on where it ran."""
     import _oracle_backend as ob
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    rendezvous = str(tmp_path / "rendezvous")             # a file of this test's own: no port to lose between probe and bind
+    procs = [ctx.Process(target=_worker, args=(r, 2, rendezvous, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(2)]

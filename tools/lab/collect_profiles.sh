@@ -13,7 +13,7 @@ done
 [ -f gpurun_out/prof_bench/bench_line.json ] && grep '^{' gpurun_out/prof_bench/bench_line.json > profiles/${r}_bench_line_under_rocprofv3.json
 mv profiles/${r}_kernel_stats_bench.csv profiles/${r}_kernel_stats_bench_py.csv 2>/dev/null
 s=gpurun_out/side
-for f in evalloop_sizes evalloop_small_ab evalloop_beyond64 trainbench configbench batchbench densebench raggedbench nutsbench_ticks ratelab potrflab selftest; do
+for f in evalloop_sizes evalloop_small_ab evalloop_beyond64 trainbench configbench batchbench densebench raggedbench nutsbench_ticks ratelab potrflab selftest fetchlab evalloop_2d sub16_ab fitrate; do
   [ -f $s/$f.txt ] && grep -v "amdgpu.ids" $s/$f.txt > profiles/${r}_$f.txt
 done
 [ -f $s/smallbench.json ] && cp $s/smallbench.json profiles/${r}_smallbench.json

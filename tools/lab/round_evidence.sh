@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 bash tools/profile.sh small_n89 89 300 1 2 > gpurun_out/prof_small_n89.log 2>&1
 for d in gpurun_out/prof_*/; do tag=$(basename $d | sed 's/^prof_//'); [ -f $d/traffic.json ] && grep -q "$(sha256sum pgmuvi_amd/libpgmuvi_hip.so | cut -c1-16)" $d/traffic.json && cp $d/traffic.json profiles/${r}_pmc_hbm_traffic_${tag}.json; done
 bash tools/lab/side_evidence.sh > gpurun_out/side.log 2>&1
+bash tools/lab/tl_sizes.sh "256 512 1024" 4 1 > gpurun_out/tls.log 2>&1 && bash tools/lab/tl_sizes.sh "250" 3 2 >> gpurun_out/tls.log 2>&1
 python3 tools/lab/soak.py > gpurun_out/soak.txt 2>&1
 ( echo "# PGM_FUZZ_CASES=120 PGM_FUZZ_SEED=7 python -m pytest tests/test_gpu_fuzz.py -m gpu -s -k random_light_curves   (library sha $(sha256sum pgmuvi_amd/libpgmuvi_hip.so | cut -c1-16))"
   PGM_FUZZ_CASES=120 PGM_FUZZ_SEED=7 python -m pytest tests/test_gpu_fuzz.py -m gpu -s -q -k random_light_curves 2>&1 | grep -E "^case|worst|passed|failed" ) > gpurun_out/fuzz_parity.txt

@@ -22,4 +22,14 @@ for a in "64 1024 2048" "128 300 1500" "32 500 3000" "16 1024 2048" "12 1024 204
 tools/selftest 1024 > $o/selftest.txt 2>&1
 [ -x tools/lab/ratelab ] && tools/lab/ratelab > $o/ratelab.txt 2>&1
 [ -x tools/lab/potrflab ] && tools/lab/potrflab 2000 > $o/potrflab.txt 2>&1
+[ -x tools/lab/fetchlab ] && tools/lab/fetchlab > $o/fetchlab.txt 2>&1
+# two input dimensions: the one launch against the launch sequence up to 128 points, the launch sequence beyond
+ev2() { echo "$1: $($2 tools/evalloop $3 $4 1 $5 1 2 | tail -1 | sed 's/  gsum.*//')  [n reps grad q batch d = $3 $4 1 $5 1 2]"; }
+( for sw in 2 0; do ev2 "PGM_SMALL=$sw" "env PGM_SMALL=$sw" 64 2000 2; ev2 "PGM_SMALL=$sw" "env PGM_SMALL=$sw" 106 2000 3; ev2 "PGM_SMALL=$sw" "env PGM_SMALL=$sw" 128 2000 4; done
+  ev2 "default" "env" 225 2000 2; ev2 "default" "env" 250 2000 3; ev2 "default" "env" 512 1000 3; ev2 "default" "env" 1000 500 3; ev2 "default" "env" 2048 100 3; ev2 "default" "env" 4096 30 3 ) > $o/evalloop_2d.txt 2>&1
+# the inverse/gradient launch of light curves of two to four block rows: sixteenth tiles (default) against quarter tiles
+( for n in 192 256 384 512 640; do for s in 0 20; do echo -n "PGM_LAUUM_SUB16=$s "; PGM_LAUUM_SUB16=$s tools/evalloop $n 1000 1 4 1 1 | tail -1; done; done
+  echo "== two input dimensions (q=3)"
+  for n in 225 250 512; do for s in 0 20; do echo -n "PGM_LAUUM_SUB16=$s "; PGM_LAUUM_SUB16=$s tools/evalloop $n 1000 1 3 1 2 | tail -1; done; done ) > $o/sub16_ab.txt 2>&1
+python3 tools/lab/fitrate.py 2>/dev/null | grep "^n=" > $o/fitrate.txt
 sha256sum pgmuvi_amd/libpgmuvi_hip.so > $o/lib_sha.txt

@@ -5,12 +5,12 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# last evaluation: from the last k_build (or k_dense_in) on
-start = max(i for i, n in enumerate(names) if "k_build" in n or "k_dense_in" in n)
+# last evaluation: from the last k_build (or k_prebuild, or k_dense_in) on
+start = max(i for i, n in enumerate(names) if "k_build" in n or "k_dense_in" in n or "k_prebuild" in n)
 ev = rows[start:]
 t0 = int(ev[0]["Start_Timestamp"])
 def short(n):
-    for key in ("k_diag", "k_trsm", "k_update_rows", "k_update", "k_lauum", "k_build", "k_finalize", "k_publish", "k_stage", "k_precompute", "k_ainv"):
+    for key in ("k_diag", "k_trsm", "k_update_rows", "k_update", "k_lauum", "k_prebuild", "k_build", "k_finalize", "k_publish", "k_stage", "k_precompute", "k_ainv"):
         if key in n: return key
     return n[:20]
 step = -1
