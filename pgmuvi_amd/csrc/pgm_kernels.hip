@@ -1852,7 +1852,10 @@ __global__ __launch_bounds__(C::NT, 2) void k_update(PgmDev P, int k0, int dp, i
 using CfgBigLds = TileCfg<128, 128, 64, 64, 2>;
 struct CfgBig : TileCfg<128, 128, 64, 64, 4, 256, KB, true> { static constexpr int LDS_DOUBLES = CfgBigLds::LDS_DOUBLES; };
 using CfgUpd = CfgBig;                                       // (8 wavefronts per 128x128 tile: measured in round 2, -0.7 %, not kept)
-using CfgSub = CfgSmall;                                     // quarter tiles of the inverse/gradient pass of short light curves
+#ifndef PGM_SUB_PF
+#define PGM_SUB_PF 8
+#endif
+using CfgSub = TileCfg<64, 64, 32, 32, PGM_SUB_PF, 256, KB, true>;   // quarter tiles of the inverse/gradient pass of short light curves (CfgSmall's shape)
 // Sixteenth tiles (round 6) for light curves of a few block rows, where the launch is a handful of work items on an otherwise
 // idle chip and its length is set by latencies, not by arithmetic (N=256, quarter tiles, ticks of the longest item: multiply
 // 14.5 us -- 64 k-steps with 8 in flight, a memory round trip per 8 --, staging 2.8, epilogue 6.8 of the launch's 25): a 32x32
