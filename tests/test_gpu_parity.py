@@ -1441,6 +1441,8 @@ def test_native_fit_of_short_light_curves_is_one_launch_per_iteration_and_the_ho
             return m, lik
         m1, l1 = build(); m2, l2 = build(); m3, l3 = build()
         r1 = train(model=m1, likelihood=l1, train_x=x, train_y=yy, maxiter=63, lr=0.01, optim="AdamW", progress=False)
+        _hip.release_workspaces()
+        monkeypatch.setenv("PGM_SMALL", "2")          # (the one launch whatever the shape: by default 96 points x 2-D x Q=3 is the launch sequence's)
         r2 = train_native(model=m2, likelihood=l2, train_x=x, train_y=yy, maxiter=63, lr=0.01, optim="AdamW", check_every=40)
         _hip.release_workspaces()
         monkeypatch.setenv("PGM_SMALL", "0")
