@@ -127,7 +127,9 @@ int pgm_mll_value_grad_f64(pgm_ws* ws, const double* x, const double* y, const d
  * evaluation -- factors, matrix, factorisation, inverse, gradient contraction, results, status -- is ONE launch, one
  * workgroup per light curve (k_small); no launch graph, nothing but the results and what pgm_predict_f64 reads later is
  * written to memory.  Same results as the launch sequence of every other size (value: the same bits; gradients: 1e-12),
- * which the environment switch PGM_SMALL=0 (read when a workspace is made) brings back.
+ * which the environment switch PGM_SMALL=0 (read when a workspace is made) brings back -- and which a call of up to 20 light
+ * curves takes by itself where it is the faster (many mixtures on 100 and more points: one CU would do all of a light
+ * curve's exponentials; the measured table is small_ok's, pgm_host.inc; PGM_SMALL=2: the one launch whatever the shape).
  */
 int pgm_mll_value_grad_batched_f64(pgm_ws* ws, int batch,
                                    const double* x, const double* y, const double* mean,

@@ -1,6 +1,5 @@
 """A/B of the one-launch path for light curves of at most 128 points (k_small, PGM_SMALL=1, the default) against the launch
-sequence of every other size (PGM_SMALL=0; 2 = the one launch whatever the shape, where the default 1 leaves ONE light curve of 113 .. 128
-points with more than four (mixture, dimension) pairs to the launch sequence), in one process on one box:
+sequence of every other size (PGM_SMALL=0; 2 = the one launch whatever the shape, where the default 1 follows small_ok's measured table), in one process on one box:
 
     python tools/smallbench.py            (GPU box)
 
