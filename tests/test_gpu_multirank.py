@@ -89,6 +89,41 @@ def test_two_ranks_on_one_gpu_equal_one_process_bit_for_bit(dev, tmp_path):
     assert owners == set(range(rag[0]))
 
 
+def test_four_ranks_with_unequal_shards_on_one_gpu(dev, tmp_path):
+    """Four ranks of one job on the one device (five processes on the card with this one: the box allows six): ten light curves
+    dealt 3 + 3 + 2 + 2, a ragged batch of nine dealt by N^3 -- every rank ends with the whole vector, bit for bit the
+    one-process result, and the gradients of its own block."""
+    total, n, chunk = 10, 256, 4
+    rag = (9, 50, 400)
+    before = _kfd_holders()
+    buf, err = io.StringIO(), open(tmp_path / "stderr.txt", "w+")
+    rc = launch.spawn_ranks([sys.executable, WORKER, "--gpus", "4", "--total-batch", str(total), "--npoints", str(n), "--chunk", str(chunk),
+                             "--ragged", *map(str, rag), "--outdir", str(tmp_path)], 4, visible_devices=launch.visible_gpu_count(),
+                            share_gpu=True, out=buf, err=err)
+    err.seek(0)
+    assert rc == 0, err.read()[-4000:]
+    line = json.loads([ln for ln in buf.getvalue().splitlines() if ln.startswith("{")][-1])
+    assert line["world"] == 4 and [r[2] for r in line["ranks"]] == [3, 3, 2, 2]
+    assert len({r[1] for r in line["ranks"]}) == 4 and _kfd_holders() == before
+    whole = make_shard(total, 0, 1, n, "cfg3", dev)
+    ref, ref_ll = sharded_batch_step(whole, total, None)
+    rwhole = make_ragged_shard(rag[0], 0, 1, rag[1], rag[2], device=dev)
+    rref, rref_ll = sharded_ragged_step(rwhole, device=dev)
+    torch.cuda.synchronize()
+    lo, owners = 0, []
+    for r in range(4):
+        got = torch.load(tmp_path / f"rank{r}.pt")
+        k = got["nloc"]
+        assert int(got["info"].abs().max()) == 0
+        assert torch.equal(got["ll"], ref_ll.cpu())                           # values: the same bits whatever the launch set
+        for key in ("g_w", "g_mu", "g_v"):                                    # gradient sums: split by the call's work items -> rounding
+            assert torch.allclose(got[key], ref[key][lo: lo + k].cpu(), rtol=1e-10, atol=1e-12), key
+        assert torch.equal(got["ragged_ll"], rref_ll.cpu())
+        owners += got["ragged_index"]
+        lo += k
+    assert lo == total and sorted(owners) == list(range(rag[0]))
+
+
 def test_chains_over_two_ranks_on_one_gpu_equal_one_process(dev, tmp_path):
     """Config 5's layout on the hardware a one-GPU box has: four chains, each on its own light curve, dealt two and two over the
     ranks of one job; each rank drives its chains through the native potential (``pgm_pot_*``) and ONE gather of the draws
