@@ -3293,12 +3293,22 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_small(PgmDev P, FitDev F) {
     //  here, or as a member of a ragged launch set through the launch sequence: thread i holds z_i^2, thread 0 also the log det,
     //  one wavefront sum per 64 points, the two added in order)
     double s_lo = zsv[lane] * zsv[lane], s_hi = zsv[lane + 64] * zsv[lane + 64];
+    // (k_finalize's products are rounded before anything is added to them -- there each is an fma onto 0.0 in a loop of its own.
+    //  Here the compiler contracted the product into the first add behind it -- the log det on lane 0, the butterfly's first step on
+    //  every lane: fma(z, z, neighbour) -- and the two paths differed in the value's last bit once in several hundred light curves;
+    //  the ragged fuzz at 120 calls x ~40 members found one (`tools/lab/ragged_repro.py 31 17 13`).  The empty asm statements keep
+    //  the products apart from the sums.)
+    asm volatile("" : "+v"(s_lo));
+    asm volatile("" : "+v"(s_hi));
     if (lane == 0) s_lo += misc[0];
     s_lo = wave_sum(s_lo); s_hi = wave_sum(s_hi);
     if (lane == 0) {
       double tot = 0.0;
       tot += s_lo; tot += s_hi;
       const double val = bad ? qnan : -0.5 * (tot + (double)n * log(2.0 * PI)) / (double)n;
+#ifdef PGM_SMALL_PEEK
+      P.partials[0] = s_lo; P.partials[1] = s_hi; P.partials[2] = tot; P.partials[3] = misc[0]; P.partials[4] = zsv[0]; P.partials[5] = val; P.partials[6] = (double)n;
+#endif
       outs[0] = val;
       P.out_small[b * P.sOut] = val;
       if (P.mll) P.mll[cb] = val;

@@ -170,3 +170,62 @@ def test_random_ragged_batches_against_their_single_evaluations():
               f"noise={'vector' if use_vec else ''}{'+scalar' if use_scalar else ''} grad={need_grad}: sets {nbs}, worst gradient deviation from the singles {worst:.2e}", flush=True)
         assert worst < 1e-10, (c, worst)
         _hip.release_workspaces()
+
+
+def test_one_launch_value_is_the_launch_sequences_bit_for_bit(monkeypatch):
+    """The one launch (k_small, forced for every shape: PGM_SMALL=2) against the launch sequence (PGM_SMALL=0) on random light curves
+    of 1 .. 128 points, 1 .. 8 mixtures, one and two input dimensions in both orders, vector and / or scalar noise: the VALUE as
+    bits -- a light curve must not change its value with the path a call's other members, or a cost rule, send it down (a member of
+    a ragged launch set takes the sequence, the same light curve alone the one launch) -- and the gradients to the rounding of their
+    differently split sums.  (Round 6: the compiler had contracted k_small's z^2 products into the first adds of its value sums,
+    which k_finalize keeps apart; one light curve in several hundred differed in the last bit.  `tools/lab/ragged_repro.py 31 17 13`.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("-m gpu tests need the MI355X")
+    dev = torch.device("cuda:0")
+    cases = int(os.environ.get("PGM_FUZZ_SMALL_CASES", "3000"))
+    gen = torch.Generator().manual_seed(int(os.environ.get("PGM_FUZZ_SEED", "20261004")) + 2)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    _hip.release_workspaces()
+    tables = {"2": {}, "0": {}}
+
+    def ws_of(sw, q, d):
+        if (q, d) not in tables[sw]:
+            monkeypatch.setenv("PGM_SMALL", sw)          # (read when a workspace is made)
+            tables[sw][(q, d)] = _hip.Workspace(dev, 128, q, d, 1)
+        return tables[sw][(q, d)]
+
+    differ, worst = [], 0.0
+    for c in range(cases):
+        n = ri(1, 128) if c % 4 else ri(97, 128)
+        d = 1 + (c % 3 == 1); q = ri(1, 8 if d == 1 else 6); order = ri(0, 1) if d == 2 else 0
+        x = torch.rand(n, d, generator=gen, dtype=D) * 600.0
+        if d == 1:
+            x = torch.sort(x[:, 0])[0].reshape(n, 1)
+        else:
+            x[:, 1] = torch.randint(1, 4, (n,), generator=gen).double() * 0.5
+        y = torch.randn(n, generator=gen, dtype=D)
+        nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+        use_vec = c % 5 != 4
+        ns = None if (use_vec and c % 2) else 0.02 + 0.1 * torch.rand((), generator=gen, dtype=D)
+        w = 0.1 + torch.rand(q, generator=gen, dtype=D)
+        mu = 0.005 + 0.3 * torch.rand(q, d, generator=gen, dtype=D)
+        v = 0.001 + 0.02 * torch.rand(q, d, generator=gen, dtype=D)
+        mean = torch.full((n,), float(torch.randn((), generator=gen, dtype=D)) * 0.3, dtype=D)
+        a = (x.to(dev), y.to(dev), mean.to(dev), nz.to(dev) if use_vec else None, None if ns is None else ns.to(dev), w.to(dev), mu.to(dev),
+             v.to(dev), order, 0.0, True)
+        one = _hip.mll_value_grad(*a, workspace=ws_of("2", q, d))
+        seq = _hip.mll_value_grad(*a, workspace=ws_of("0", q, d))
+        torch.cuda.synchronize()
+        assert int(one["info"]) == 0 and int(seq["info"]) == 0, (c, n, q, d)
+        if float(one["mll"]) != float(seq["mll"]):
+            differ.append((c, n, q, d, order, float(one["mll"]), float(seq["mll"])))
+        for k in ("g_w", "g_mu", "g_v", "g_mean", "g_noise"):
+            worst = max(worst, float((one[k] - seq[k]).abs().max()) / (float(seq[k].abs().max()) + 1e-300))
+    for table in tables.values():
+        for ws in table.values():
+            ws.close()
+    monkeypatch.delenv("PGM_SMALL", raising=False)
+    _hip.release_workspaces()
+    print(f"{cases} light curves: {len(differ)} values differ in their bits; worst gradient deviation {worst:.2e}")
+    assert not differ, differ[:5]
+    assert worst < 1e-9
