@@ -1,0 +1,127 @@
+"""Wider random checks of paths the test suite holds at a few fixed shapes (round 6, after a wider fuzz found a last-bit inconsistency):
+
+  batches     equal-length batches of 2 .. 40 light curves x 129 .. 1500 points (fused sweep with windows, k_trsm64, panel sweep):
+              every member's value is its single evaluation's, bit for bit; gradients to rounding (log-parameter metric)
+  potential   pgm_pot_* (z -> theta, priors, Jacobians, chain rule on the device) against the same potential assembled on the host,
+              random chains x points x mixtures x dimensions, fixed and learned noise, a few ticks each
+  predict     posterior mean / variance after an evaluation, random sizes 1 .. 1500 (one launch, sixteenth tiles, fused sweep) and
+              random test points, against the oracle's dense posterior
+
+    python tools/lab/fuzz_more.py [batches|potential|predict|all] [cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from pgmuvi_amd import _hip, mcmc  # noqa: E402
+from oracle import sm_mll_oracle as orc  # noqa: E402
+
+D = torch.float64
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(seed)
+ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+bad = 0
+
+
+def curve(n, d, q):
+    x = torch.rand(n, d, generator=gen, dtype=D) * 900.0
+    if d == 1:
+        x = torch.sort(x[:, 0])[0].reshape(n, 1)
+    else:
+        x[:, 1] = torch.randint(1, 4, (n,), generator=gen).double() * 0.5
+    y = torch.randn(n, generator=gen, dtype=D)
+    nz = 0.01 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+    w = 0.1 + torch.rand(q, generator=gen, dtype=D)
+    mu = 0.005 + 0.3 * torch.rand(q, d, generator=gen, dtype=D)
+    v = 0.001 + 0.02 * torch.rand(q, d, generator=gen, dtype=D)
+    return x, y, nz, w, mu, v
+
+
+def hyper_dev(a, r, w, mu, v):
+    cat = lambda g: torch.cat([g["g_w"].cpu().reshape(-1) * w.reshape(-1), g["g_mu"].cpu().reshape(-1) * mu.reshape(-1), g["g_v"].cpu().reshape(-1) * v.reshape(-1)])
+    va, vr = cat(a), cat(r)
+    return float((va - vr).abs().max() / (vr.abs().max() + 1e-300))
+
+
+if what in ("batches", "all"):
+    worst = 0.0
+    for c in range(cases):
+        B = ri(2, 40) if c % 3 else ri(2, 12)
+        n = ri(129, 1500) if c % 2 else ri(129, 700)
+        d = 1 + (c % 5 == 1); q = ri(1, 4); order = ri(0, 1) if d == 2 else 0
+        cs = [curve(n, d, q) for _ in range(B)]
+        st = lambda i: torch.stack([t[i] for t in cs]).to(dev)
+        out = _hip.mll_value_grad(st(0), st(1), torch.full((B, n), 0.1, dtype=D, device=dev), st(2), None, st(3), st(4), st(5), order, 0.0, True)
+        torch.cuda.synchronize()
+        res = {k: out[k].clone() for k in ("mll", "g_w", "g_mu", "g_v", "g_noise", "g_mean", "info")}
+        assert int(res["info"].abs().max()) == 0
+        for b in range(B):
+            x, y, nz, w, mu, v = cs[b]
+            s = _hip.mll_value_grad(x.to(dev), y.to(dev), torch.full((n,), 0.1, dtype=D, device=dev), nz.to(dev), None, w.to(dev), mu.to(dev), v.to(dev), order, 0.0, True)
+            torch.cuda.synchronize()
+            if float(s["mll"]) != float(res["mll"][b]):
+                bad += 1
+                print(f"batches: call {c} (B={B} n={n} q={q} d={d} order={order}) member {b}: value {float(res['mll'][b])!r} in the batch, {float(s['mll'])!r} alone")
+            worst = max(worst, hyper_dev({k: res[k][b] for k in ("g_w", "g_mu", "g_v")}, s, w, mu, v))
+            worst = max(worst, float((res["g_noise"][b] - s["g_noise"]).abs().max() / s["g_noise"].abs().max()))
+        _hip.release_workspaces()
+    print(f"batches: {cases} calls, {bad} members' values differ from their single evaluation in their bits; worst gradient deviation {worst:.2e}")
+
+if what in ("potential", "all"):
+    rng = np.random.default_rng(seed)
+    worst_u, worst_g, nb = 0.0, 0.0, 0
+    for c in range(cases):
+        C = ri(1, 8); n = ri(20, 900) if c % 3 else ri(20, 128); Q = ri(1, 4); d = 1 + (c % 4 == 1); learn = c % 3 == 2
+        cs = [curve(n, d, Q) for _ in range(C)]
+        xx = torch.stack([t[0] for t in cs]); y = torch.stack([t[1] for t in cs]); nz = torch.stack([t[2] for t in cs])
+        native = mcmc.SMPotential(xx.to(dev), y.to(dev), None if learn else nz.to(dev), num_mixtures=Q)
+        host = mcmc.SMPotential(xx.to(dev), y.to(dev), None if learn else nz.to(dev), num_mixtures=Q)
+        host._use_native = False
+        assert native._use_native
+        for tick in range(3):
+            z = rng.normal(0, 0.3, (C, native.P))
+            z[:, 1 + Q:1 + Q + Q * d] += np.log(1 / 120.0)
+            z[:, 1 + Q + Q * d:1 + Q + 2 * Q * d] += np.log(1 / 1200.0)
+            if learn:
+                z[:, -1] = np.log(0.02)
+            Un, Gn = native(z); Uh, Gh = host(z)
+            ok = np.isfinite(Un).all() and np.allclose(Un, Uh, rtol=1e-12, atol=1e-9) and np.allclose(Gn, Gh, rtol=1e-9, atol=1e-9 * n)
+            worst_u = max(worst_u, float(np.abs(Un - Uh).max())); worst_g = max(worst_g, float(np.abs(Gn - Gh).max() / (np.abs(Gh).max() + 1e-300)))
+            if not ok:
+                nb += 1
+                print(f"potential: case {c} (C={C} n={n} Q={Q} d={d} learn={learn}) tick {tick}: max |dU| {np.abs(Un - Uh).max():.3e}, gradient {np.abs(Gn - Gh).max():.3e}")
+        del native, host
+        _hip.release_workspaces()
+    bad += nb
+    print(f"potential: {cases} cases x 3 ticks, {nb} outside tolerance; worst |dU| {worst_u:.2e}, worst gradient deviation {worst_g:.2e} (relative to the largest entry)")
+
+if what in ("predict", "all"):
+    worst_m, worst_v, nb = 0.0, 0.0, 0
+    for c in range(cases):
+        n = ri(1, 128) if c % 3 == 0 else (ri(129, 520) if c % 3 == 1 else ri(521, 1500))
+        q = ri(1, 4); m = ri(1, 700)
+        x, y, nz, w, mu, v = curve(n, 1, q)
+        ws = _hip.Workspace(dev, n, q, 1, 1)
+        out = _hip.mll_value_grad(x.to(dev), y.to(dev), torch.full((n,), 0.2, dtype=D, device=dev), nz.to(dev), None, w.to(dev), mu.to(dev), v.to(dev), 0, 0.0, True, workspace=ws)
+        assert int(out["info"]) == 0
+        xs = torch.rand(m, generator=gen, dtype=D) * 1000.0 - 50.0
+        pm, pv = _hip.predict(ws, xs.reshape(-1, 1).to(dev), torch.full((m,), 0.2, dtype=D, device=dev))
+        torch.cuda.synchronize()
+        rm, rv = orc.posterior(x[:, 0], y, 0.2, nz, w, mu, v, xs, 0.2)
+        dm, dv = float((pm.cpu() - rm).abs().max()), float((pv.cpu() - rv).abs().max())
+        worst_m, worst_v = max(worst_m, dm), max(worst_v, dv)
+        if not (dm < 1e-8 and dv < 1e-8):
+            nb += 1
+            print(f"predict: case {c} (n={n} q={q} m={m}): max |d mean| {dm:.3e}, max |d var| {dv:.3e}")
+        ws.close()
+    bad += nb
+    print(f"predict: {cases} cases, {nb} outside 1e-8; worst |d mean| {worst_m:.2e}, worst |d var| {worst_v:.2e}")
+
+sys.exit(1 if bad else 0)
