@@ -7,7 +7,11 @@
   predict     posterior mean / variance after an evaluation, random sizes 1 .. 1500 (one launch, sixteenth tiles, fused sweep) and
               random test points, against the oracle's dense posterior
 
-    python tools/lab/fuzz_more.py [batches|potential|predict|all] [cases] [seed]
+  fit         the device-resident optimiser loop (pgm_fit_*: one launch per iteration up to 128 points, fused fit launches and several
+              iterations per graph replay beyond) against the reference-shaped host loop ``train``: random sizes 10 .. 1300, 1 .. 4
+              mixtures, 1-D / 2-D, SGD / Adam / AdamW, fixed or learned noise, constant or linear mean, 5 .. 70 iterations
+
+    python tools/lab/fuzz_more.py [batches|potential|predict|fit|all] [cases] [seed]
 """
 import os
 import sys
@@ -123,5 +127,63 @@ if what in ("predict", "all"):
         ws.close()
     bad += nb
     print(f"predict: {cases} cases, {nb} outside 1e-8; worst |d mean| {worst_m:.2e}, worst |d var| {worst_v:.2e}")
+
+if what in ("fit", "all"):
+    from pgmuvi_amd import gpytorch as g
+    from pgmuvi_amd.trainers import train, train_native
+    worst, nb, diverged = 0.0, 0, 0
+    for c in range(cases):
+        n = ri(10, 128) if c % 3 == 0 else (ri(129, 520) if c % 3 == 1 else ri(521, 1300))
+        d = 1 + (c % 4 == 1); Q = ri(1, 4); learn = c % 5 == 2; mean = "linear" if c % 7 == 3 else "constant"
+        optim = ("SGD", "Adam", "AdamW")[c % 3] if mean == "constant" else ("Adam", "AdamW")[c % 2]; iters = ri(5, 70); lr = 1e-4 if optim == "SGD" else 0.01
+        x, y, nz, w, mu, v = curve(n, d, Q)
+        xd, yd, nzd = (x[:, 0] if d == 1 else x).to(dev), y.to(dev), nz.to(dev)
+
+        def build():
+            lik = g.likelihoods.GaussianLikelihood().double().to(dev) if learn else g.likelihoods.FixedNoiseGaussianLikelihood(nzd)
+
+            class Model(g.models.ExactGP):
+                def __init__(self):
+                    super().__init__(xd, yd, lik)
+                    self.mean_module = g.means.ConstantMean() if mean == "constant" else g.means.LinearMean(input_size=d)
+                    self.covar_module = g.kernels.SpectralMixtureKernel(num_mixtures=Q, ard_num_dims=d)
+
+                def forward(self, xx):
+                    return g.distributions.MultivariateNormal(self.mean_module(xx), self.covar_module(xx))
+
+            m = Model().double().to(dev)
+            if mean == "linear":
+                with torch.no_grad():
+                    m.mean_module.weights.fill_(1e-4); m.mean_module.bias.fill_(0.05)
+            m.initialize(**{"covar_module.mixture_weights": w.to(dev), "covar_module.mixture_means": mu.reshape(Q, 1, d).to(dev),
+                            "covar_module.mixture_scales": v.reshape(Q, 1, d).to(dev)})
+            if learn:
+                lik.noise = torch.tensor(0.03, dtype=D, device=dev)
+            return m, lik
+
+        m1, l1 = build(); m2, l2 = build()
+        try:
+            r1 = train(model=m1, likelihood=l1, train_x=xd, train_y=yd, maxiter=iters, lr=lr, optim=optim, progress=False, stop=None)
+            r2 = train_native(model=m2, likelihood=l2, train_x=xd, train_y=yd, maxiter=iters, lr=lr, optim=optim, check_every=max(4, iters // 2), stop=None)
+        except Exception as exc:                                 # (a diverging fit ends in a matrix that cannot be factored)
+            if "positive definite" not in str(exc) and "NaN" not in str(exc):
+                raise
+            diverged += 1
+            _hip.release_workspaces()
+            continue
+        a, b = np.array(r1["loss"], dtype=float), np.array(r2["loss"], dtype=float)
+        if len(a) == len(b) and np.abs(a).max() > 1e6:          # (SGD on a linear mean of times up to 900: the fit itself diverges, rounding differences with it)
+            diverged += 1
+            _hip.release_workspaces()
+            continue
+        dl = float((np.abs(a - b) / np.maximum(1.0, np.abs(a))).max()) if len(a) == len(b) else float("inf")
+        dp = max(float((p1.detach() - p2.detach()).abs().max() / (p2.detach().abs().max() + 1e-12)) for (_, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()))
+        worst = max(worst, dl)
+        if not (dl < 1e-8 and dp < 1e-7):
+            nb += 1
+            print(f"fit: case {c} (n={n} d={d} Q={Q} learn={learn} mean={mean} {optim} x{iters}): max |d loss| {dl:.3e}, parameters {dp:.3e}")
+        _hip.release_workspaces()
+    bad += nb
+    print(f"fit: {cases} cases ({diverged} left out: the optimisation itself diverged), {nb} outside tolerance; worst |d loss| / max(1, |loss|) along the trajectories {worst:.2e}")
 
 sys.exit(1 if bad else 0)
