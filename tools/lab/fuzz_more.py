@@ -11,7 +11,11 @@
               iterations per graph replay beyond) against the reference-shaped host loop ``train``: random sizes 10 .. 1300, 1 .. 4
               mixtures, 1-D / 2-D, SGD / Adam / AdamW, fixed or learned noise, constant or linear mean, 5 .. 70 iterations
 
-    python tools/lab/fuzz_more.py [batches|potential|predict|fit|all] [cases] [seed]
+  generic     composed stationary kernels (the zoo of tests/test_gpu_parity.py: Matern / RBF / RQ / periodic / cosine / linear / constant
+              under scale, product, sum; active dimensions in 2-D) at random sizes 5 .. 1600 and randomly perturbed parameters, fused
+              path against the oracle's torch formulas with autograd
+
+    python tools/lab/fuzz_more.py [batches|potential|predict|fit|generic|all] [cases] [seed]
 """
 import os
 import sys
@@ -185,5 +189,36 @@ if what in ("fit", "all"):
         _hip.release_workspaces()
     bad += nb
     print(f"fit: {cases} cases ({diverged} left out: the optimisation itself diverged), {nb} outside tolerance; worst |d loss| / max(1, |loss|) along the trajectories {worst:.2e}")
+
+if what in ("generic", "all"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle_backend as ob
+    import test_gpu_parity as tp
+    from pgmuvi_amd.gpytorch.kernels import compile_program
+    worst_v, worst_g, nb = 0.0, 0.0, 0
+    zoo = [(d, name, k) for d in (1, 2) for name, k in tp._kernel_zoo(d).items()]
+    for c in range(cases):
+        d, name, kern = zoo[c % len(zoo)]
+        prog = compile_program(kern, d)
+        theta = prog.theta().detach() * torch.exp(0.3 * torch.randn(prog.theta().numel(), generator=gen, dtype=D))
+        n = ri(5, 128) if c % 4 == 0 else (ri(129, 700) if c % 4 < 3 else ri(701, 1600))
+        x = torch.rand(n, d, generator=gen, dtype=D) * torch.tensor([300.0, 2.0][:d], dtype=D)
+        x = x[torch.argsort(x[:, 0])]
+        y = torch.randn(n, generator=gen, dtype=D)
+        nz = 0.02 + 0.05 * torch.rand(n, generator=gen, dtype=D)
+        mean = torch.full((n,), 0.1, dtype=D)
+        out = _hip.mll_kernel_value_grad(x.to(dev), y.to(dev), mean.to(dev), nz.to(dev), torch.tensor(0.01, dtype=D, device=dev), prog, theta.to(dev))
+        ref = ob.mll_kernel_value_grad(x, y, mean, nz, torch.tensor(0.01, dtype=D), prog, theta)
+        dv = abs(float(out["mll"]) - float(ref["mll"]))
+        gt = out["g_theta"].cpu() * theta; rt = ref["g_theta"] * theta                 # (log-parameter metric, one vector)
+        dg = float((gt - rt).abs().max() / (rt.abs().max() + 1e-300))
+        dn = float((out["g_noise"].cpu() - ref["g_noise"]).abs().max() / (ref["g_noise"].abs().max() + 1e-300))
+        worst_v, worst_g = max(worst_v, dv), max(worst_g, dg, dn)
+        if not (int(out["info"]) == 0 and dv < 1e-9 and dg < 1e-7 and dn < 1e-7):
+            nb += 1
+            print(f"generic: case {c} ({name}, d={d}, n={n}): |d mll| {dv:.3e}, theta gradient {dg:.3e}, noise gradient {dn:.3e}, info {int(out['info'])}")
+        _hip.release_workspaces()
+    bad += nb
+    print(f"generic: {cases} cases, {nb} outside tolerance; worst |d mll| {worst_v:.2e}, worst gradient deviation {worst_g:.2e}")
 
 sys.exit(1 if bad else 0)
