@@ -2203,3 +2203,50 @@ def test_performance_guards(dev):
     report.append(f"ragged 64 x N ~ U{{1024..2048}}: {best:.3f} ms (guard {1.2 * 8.4:.3f})")
     assert best < 1.2 * 8.4, f"ragged 64 x N ~ U{{1024..2048}}: {best:.2f} ms per call (8.4 ms measured; the padded sets take 10.2)"
     print("performance guards: " + "; ".join(report))
+
+
+@pytest.mark.parametrize("shape", [(1, 89, 2, 1), (1, 250, 3, 2), (3, 300, 3, 1), (1, 1450, 2, 1), (8, 2048, 4, 1), (18, 1450, 2, 1), (12, 100, 2, 1)])
+def test_results_do_not_depend_on_what_a_new_workspaces_memory_holds(dev, monkeypatch, shape):
+    """A new workspace's buffers hold whatever the allocator hands out: zero pages in a fresh process, the remains of freed
+    tensors and workspaces in a long-running one.  ``PGM_POISON=1`` (read by ``pgm_workspace_create``) fills every buffer with
+    0xFF bytes -- NaN as doubles, -1 as integers, an unmapped address as a pointer -- so a kernel that reads what nobody wrote
+    shows: value and every gradient of the first and of later evaluations on a poisoned workspace must be the bits a normal
+    workspace gives (one launch, sixteenth tiles, fused sweep with build-beside and windows, panel sweep with the 64-column row solve)."""
+    B, n, q, d = shape
+    gen = torch.Generator().manual_seed(B * 1000 + n)
+    x = torch.sort(torch.rand(B, n, generator=gen, dtype=D) * 900, dim=1)[0].unsqueeze(-1)
+    if d == 2:
+        x = torch.cat([x, torch.randint(1, 4, (B, n, 1), generator=gen).double() * 0.5], dim=-1)
+    y = torch.randn(B, n, generator=gen, dtype=D)
+    nz = 0.01 + 0.05 * torch.rand(B, n, generator=gen, dtype=D)
+    w = 0.1 + torch.rand(B, q, generator=gen, dtype=D)
+    mu = 0.005 + 0.3 * torch.rand(B, q, d, generator=gen, dtype=D)
+    v = 0.001 + 0.02 * torch.rand(B, q, d, generator=gen, dtype=D)
+    a = [t.to(dev) for t in (x, y, torch.zeros(B, n, dtype=D), nz)] + [None] + [t.to(dev) for t in (w, mu, v)]
+    if B == 1:
+        a = [None if t is None else t[0] for t in a]
+    _hip.release_workspaces()
+    keys = ("mll", "g_w", "g_mu", "g_v", "g_noise", "g_mean", "info")
+    plain = _hip.Workspace(dev, n, q, d, B)
+    ref = _hip.mll_value_grad(*a, 0, 0.0, True, workspace=plain)
+    torch.cuda.synchronize()
+    ref = {k: ref[k].clone() for k in keys}
+    plain.close()
+    assert int(ref["info"].abs().max()) == 0
+    monkeypatch.setenv("PGM_POISON", "1")
+    poisoned = _hip.Workspace(dev, n, q, d, B)
+    monkeypatch.delenv("PGM_POISON")
+    for rep in range(3):
+        out = _hip.mll_value_grad(*a, 0, 0.0, True, workspace=poisoned)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(out[k], ref[k]), (shape, rep, k)
+    # prediction reads the factor, the inverse images and z of that workspace
+    if B == 1:
+        xs = torch.linspace(-5.0, 905.0, 130, dtype=D).reshape(-1, 1)
+        if d == 2:
+            xs = torch.cat([xs, torch.full((130, 1), 1.0, dtype=D)], dim=-1)
+        pm, pv = _hip.predict(poisoned, xs.to(dev), torch.zeros(130, dtype=D, device=dev))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(pm).all()) and bool(torch.isfinite(pv).all())
+    poisoned.close()
