@@ -13,6 +13,7 @@ for f in soak fuzz_parity fuzz_ragged; do grep -v amdgpu.ids gpurun_out/$f.txt >
 [ -f gpurun_out/nutsconv.txt ] && grep -v amdgpu.ids gpurun_out/nutsconv.txt > profiles/${r}_nuts_config5_convergence.txt
 [ -f gpurun_out/fuzz300.txt ] && grep -v amdgpu.ids gpurun_out/fuzz300.txt > profiles/${r}_fuzz_parity_300.txt
 [ -f gpurun_out/fuzz_ragged_120.txt ] && grep -v amdgpu.ids gpurun_out/fuzz_ragged_120.txt > profiles/${r}_fuzz_ragged_120.txt
+[ -f gpurun_out/random_soak.txt ] && grep -v amdgpu.ids gpurun_out/random_soak.txt > profiles/${r}_random_soak.txt
 [ -f gpurun_out/fuzz_bits_wide.txt ] && grep -v amdgpu.ids gpurun_out/fuzz_bits_wide.txt > profiles/${r}_fuzz_bits_wide.txt
 for d in gpurun_out/tls_*/; do [ -d "$d" ] || continue; k=$(find $d -name '*kernel_trace.csv' -newer pgmuvi_amd/libpgmuvi_hip.so | head -1); [ -n "$k" ] && python3 tools/timeline.py "$k" > profiles/${r}_timeline_$(basename $d | sed 's/^tls_//').txt; done
 ls profiles | grep -c ${r}_; grep -h "_lib_sha16" profiles/${r}_pmc_hbm_traffic_*.json | sort | uniq -c; sha256sum pgmuvi_amd/libpgmuvi_hip.so | cut -c1-16

@@ -22,6 +22,7 @@ python3 tools/lab/soak.py > gpurun_out/soak.txt 2>&1
   PGM_FUZZ_RAGGED_CASES=120 PGM_FUZZ_SEED=31 timeout -k 10 600 python -m pytest tests/test_gpu_fuzz.py -m gpu -s -q -k ragged 2>&1 | grep -E "^ragged case|passed|failed" ) > gpurun_out/fuzz_ragged_120.txt
 ( echo "# PGM_FUZZ_SEED=77 PGM_FUZZ_SWITCH_CASES=3000 PGM_FUZZ_SMALL_CASES=20000 python -m pytest tests/test_gpu_fuzz.py -m gpu -s -k 'plainest or one_launch_value'   (library sha $(sha256sum pgmuvi_amd/libpgmuvi_hip.so | cut -c1-16))"
   PGM_FUZZ_SEED=77 PGM_FUZZ_SWITCH_CASES=3000 PGM_FUZZ_SMALL_CASES=20000 timeout -k 10 600 python -m pytest tests/test_gpu_fuzz.py -m gpu -s -q -k "plainest or one_launch_value" 2>&1 | grep -E "light curves:|passed|failed" ) > gpurun_out/fuzz_bits_wide.txt
+( echo "# python tools/lab/random_soak.py 4000 8   (library sha $(sha256sum pgmuvi_amd/libpgmuvi_hip.so | cut -c1-16))"; timeout -k 10 600 python3 tools/lab/random_soak.py 4000 8 2>&1 | grep -v "amdgpu\|Warning\|warn\|ystd" ) > gpurun_out/random_soak.txt
 tail -1 gpurun_out/soak.txt; tail -2 gpurun_out/fuzz_parity.txt; tail -1 gpurun_out/fuzz_ragged.txt
 python3 -c "
 import json; d=json.load(open('gpurun_out/side/bench_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['reference_published_workload']['train_native']['it_per_s'])"
