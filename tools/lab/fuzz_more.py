@@ -15,7 +15,10 @@
               under scale, product, sum; active dimensions in 2-D) at random sizes 5 .. 1600 and randomly perturbed parameters, fused
               path against the oracle's torch formulas with autograd
 
-    python tools/lab/fuzz_more.py [batches|potential|predict|fit|generic|all] [cases] [seed]
+  ls          Lomb-Scargle periodograms: exact sums on random grids and the FFT approximation on regular ones, random light curves of
+              5 .. 3000 points (batches of 1 .. 6), with and without error bars, fit_mean / center_data, against the numpy oracle
+
+    python tools/lab/fuzz_more.py [batches|potential|predict|fit|generic|ls|all] [cases] [seed]
 """
 import os
 import sys
@@ -220,5 +223,32 @@ if what in ("generic", "all"):
         _hip.release_workspaces()
     bad += nb
     print(f"generic: {cases} cases, {nb} outside tolerance; worst |d mll| {worst_v:.2e}, worst gradient deviation {worst_g:.2e}")
+
+if what in ("ls", "all"):
+    from oracle import ls_oracle as lso
+    worst, nb = 0.0, 0
+    for c in range(cases):
+        B = ri(1, 6); n = ri(5, 200) if c % 3 == 0 else ri(201, 3000)
+        t = torch.sort(torch.rand(B, n, generator=gen, dtype=D) * ri(50, 3000), dim=1)[0]
+        y = torch.randn(B, n, generator=gen, dtype=D) + 0.7 * torch.sin(2 * np.pi * t / ri(5, 400))
+        with_dy = c % 2 == 0
+        dy = (0.05 + 0.3 * torch.rand(B, n, generator=gen, dtype=D)) if with_dy else None
+        fit_mean = c % 5 != 4; center = True if not fit_mean else (c % 3 != 2)
+        nf = ri(20, 1500)
+        f0, df = 1e-4 + 1e-3 * float(torch.rand((), generator=gen)), (0.5 + float(torch.rand((), generator=gen))) / (float(t.max()) * 5)
+        freq = torch.as_tensor(f0 + df * np.arange(nf), dtype=D)
+        out = _hip.lomb_scargle(t.to(dev), y.to(dev), None if dy is None else dy.to(dev), freq.to(dev), fit_mean, center).cpu().numpy()
+        fast = _hip.lomb_scargle_fast(t.to(dev), y.to(dev), None if dy is None else dy.to(dev), f0, df, nf, fit_mean, center).cpu().numpy()
+        for b in range(B):
+            tb, yb, db = t[b].numpy(), y[b].numpy(), None if dy is None else dy[b].numpy()
+            ref = lso.power(tb, yb, db, freq.numpy(), fit_mean, center)
+            reff = lso.power_fast(tb, yb, db, f0, df, nf, fit_mean, center)
+            d1, d2 = float(np.abs(out[b] - ref).max()), float(np.abs(fast[b] - reff).max())
+            worst = max(worst, d1, d2)
+            if not (d1 < 1e-9 and d2 < 1e-9):
+                nb += 1
+                print(f"ls: case {c} (B={B} n={n} nf={nf} dy={with_dy} fit_mean={fit_mean} center={center}) curve {b}: exact sums {d1:.3e}, FFT form {d2:.3e}")
+    bad += nb
+    print(f"ls: {cases} cases, {nb} periodograms outside 1e-9; worst deviation {worst:.2e}")
 
 sys.exit(1 if bad else 0)
