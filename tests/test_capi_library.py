@@ -176,3 +176,52 @@ def test_the_plan_check_notices_a_damaged_plan():
     for nb in (8, 16, 32, 40, 48):
         assert f(nb, 1, 1, 0, 1, -1, -1, 0, 0) == 0
         assert (f(nb, 1, 1, 0, 1, -1, -1, 0, 3) > 0) == (nb >= 32)
+
+
+def _decisions(n, q, d, batch, need_grad=1):
+    f = ctypes.CDLL(_hip.lib_path()).pgm_debug_decisions
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    out = (ctypes.c_int * 8)()
+    rc = f(n, q, d, batch, need_grad, out)
+    return rc, dict(one_launch=out[0], block_rows=out[1], k_blocks_per_item=out[2], items=out[3], workgroups_per_item=out[4])
+
+
+def test_which_way_a_call_goes_host_logic_of_round_6(monkeypatch):
+    """Host logic, no GPU (`pgm_debug_decisions`): the one launch or the launch sequence for light curves of at most 128 points
+    (small_ok's measured table: by input dimensions, rows of 16x16 sub-blocks and mixtures, for up to 20 light curves per call),
+    and the split of the inverse/gradient pass -- k-blocks per work item, whole / quarter / sixteenth tiles -- by block rows and
+    light curves per call; the switches that bring the other paths back."""
+    for k_ in ("PGM_SMALL", "PGM_LAUUM_SUB", "PGM_LAUUM_SUB16"):
+        monkeypatch.delenv(k_, raising=False)
+    one = lambda *a: _decisions(*a)[1]["one_launch"]
+    # the reference's published workload and the small sizes: one launch whatever the mixtures
+    assert one(89, 2, 1, 1) == 1 and one(89, 4, 1, 1) == 1 and one(17, 16, 1, 1) == 1 and one(64, 8, 2, 1) == 1 and one(1, 1, 1, 1) == 1
+    # 1-D: 9 / 6 / 2 mixtures at 6 / 7 / 8 rows of sub-blocks
+    assert [one(96, q, 1, 1) for q in (9, 10)] == [1, 0] and [one(112, q, 1, 1) for q in (6, 7)] == [1, 0] and [one(128, q, 1, 1) for q in (2, 3)] == [1, 0]
+    # 2-D: 7 / 2 / 1 / 0 at 5 .. 8 rows (the Lomb-Scargle notebook's 106 points in three bands, Q=3: the launch sequence)
+    assert [one(80, q, 2, 1) for q in (7, 8)] == [1, 0] and [one(96, q, 2, 1) for q in (2, 3)] == [1, 0]
+    assert [one(106, q, 2, 1) for q in (1, 2, 3)] == [1, 0, 0] and one(128, 1, 2, 1) == 0
+    # the table holds for up to 20 light curves per call; beyond, every shape takes the one launch; 129 points never do
+    assert one(128, 4, 1, 20) == 0 and one(128, 4, 1, 21) == 1 and one(128, 8, 2, 512) == 1 and one(129, 1, 1, 1) == 0
+    monkeypatch.setenv("PGM_SMALL", "2")
+    assert one(128, 16, 1, 1) == 1 and one(128, 8, 2, 1) == 1
+    monkeypatch.setenv("PGM_SMALL", "0")
+    assert one(17, 1, 1, 1) == 0 and one(89, 2, 1, 512) == 0
+    monkeypatch.delenv("PGM_SMALL")
+    # the inverse/gradient pass: one k-block per item and sixteenth tiles for 2 .. 4 block rows while the call has <= 20 items
+    lau = lambda *a: tuple(_decisions(*a)[1][k] for k in ("block_rows", "k_blocks_per_item", "items", "workgroups_per_item"))
+    assert lau(256, 4, 1, 1) == (2, 1, 4, 16) and lau(250, 3, 2, 1) == (2, 1, 4, 16) and lau(512, 4, 1, 1) == (4, 1, 20, 16)
+    assert lau(256, 2, 1, 4) == (2, 1, 4, 16) and lau(256, 2, 1, 5) == (2, 1, 4, 16)                     # 4 items x 5 light curves = 20
+    assert lau(256, 2, 1, 6) == (2, 2, 3, 16) and lau(256, 2, 1, 7) == (2, 2, 3, 4)                       # 24 > 20: round 5's split of two; 3 x 6 = 18 still sixteenths, 21: quarters
+    assert lau(128, 4, 1, 1) == (1, 1, 1, 16)                                   # (the launch sequence of <= 128 points: one item)
+    assert lau(640, 4, 1, 1)[3] == 4 and lau(1024, 4, 1, 1)[3] == 4              # five block rows and more: quarter tiles (<= 128 items)
+    assert lau(2048, 4, 1, 1)[3] == 4 and lau(3000, 4, 1, 1)[3] == 4 and lau(4096, 4, 1, 1)[3] == 1       # 13 .. 24 block rows: quarter; beyond: whole
+    assert lau(2048, 4, 1, 8)[3] == 1 and lau(2048, 4, 1, 512) == (16, 16, 136, 1)                       # batches: whole tiles, one item per tile from 64 light curves on
+    assert _decisions(256, 4, 1, 1, 0)[1]["workgroups_per_item"] == 1            # value only: no such pass
+    monkeypatch.setenv("PGM_LAUUM_SUB16", "0")
+    assert lau(256, 4, 1, 1)[1:] == (2, 3, 4)                                    # round 5's form: k-split of two, quarter tiles
+    monkeypatch.setenv("PGM_LAUUM_SUB", "0")
+    assert lau(256, 4, 1, 1)[3] == 1 and lau(2048, 4, 1, 1)[3] == 1
+    # bad arguments
+    assert _decisions(0, 1, 1, 1)[0] == -1 and _decisions(100, 17, 1, 1)[0] == -1 and _decisions(100, 1, 3, 1)[0] == -1 and _decisions(20000, 1, 1, 1)[0] == -1
