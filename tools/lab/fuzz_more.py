@@ -18,7 +18,10 @@
   ls          Lomb-Scargle periodograms: exact sums on random grids and the FFT approximation on regular ones, random light curves of
               5 .. 3000 points (batches of 1 .. 6), with and without error bars, fit_mean / center_data, against the numpy oracle
 
-    python tools/lab/fuzz_more.py [batches|potential|predict|fit|generic|ls|all] [cases] [seed]
+  dense       the dense entry points: pgm_sm_kernel_f64 (rectangular K(x1, x2), both dimension orders) against the oracle's matrix, and
+              pgm_mll_dense_f64 / pgm_predict_dense_f64 (a caller-built matrix through the sweep, dmll/dA by autograd on the oracle)
+
+    python tools/lab/fuzz_more.py [batches|potential|predict|fit|generic|ls|dense|all] [cases] [seed]
 """
 import os
 import sys
@@ -250,5 +253,39 @@ if what in ("ls", "all"):
                 print(f"ls: case {c} (B={B} n={n} nf={nf} dy={with_dy} fit_mean={fit_mean} center={center}) curve {b}: exact sums {d1:.3e}, FFT form {d2:.3e}")
     bad += nb
     print(f"ls: {cases} cases, {nb} periodograms outside 1e-9; worst deviation {worst:.2e}")
+
+if what in ("dense", "all"):
+    worst_k, worst_v, worst_g, worst_p, nb = 0.0, 0.0, 0.0, 0.0, 0
+    for c in range(cases):
+        n = ri(1, 128) if c % 3 == 0 else ri(129, 900); m = ri(1, 400); d = 1 + (c % 2); q = ri(1, 4); order = ri(0, 1) if d == 2 else 0
+        x, y, nz, w, mu, v = curve(n, d, q)
+        x2 = torch.rand(m, d, generator=gen, dtype=D) * 900.0
+        if d == 2: x2[:, 1] = torch.randint(1, 4, (m,), generator=gen).double() * 0.5
+        Kd = _hip.sm_kernel_dense(x.to(dev), x2.to(dev), w.to(dev), mu.to(dev), v.to(dev), None, 0.0, order).cpu()
+        Kr = orc.sm_kernel(x, x2, w, mu, v, order)
+        dk = float((Kd - Kr).abs().max())
+        # the dense back-end on A = K(x, x) + noise
+        A = (orc.sm_kernel(x, x, w, mu, v, order) + torch.diag(nz)).requires_grad_(True)
+        r = (y - 0.1)
+        val = orc.mll_dense(A, y, 0.1, torch.zeros(n, dtype=D))
+        val.backward()
+        ws = _hip.Workspace(dev, n, 1, 1, 1)
+        out = _hip.mll_dense(A.detach().to(dev), r.to(dev), 0.0, True, workspace=ws)
+        torch.cuda.synchronize()
+        dv = abs(float(out["mll"]) - float(val))
+        ga = out["g_a"].cpu().reshape(n, n); gr = A.grad
+        gsym = 0.5 * (gr + gr.T)                                 # (the library returns the symmetric dmll/dA)
+        dg = float((ga - gsym).abs().max() / (gsym.abs().max() + 1e-300))
+        pm, pv = _hip.predict_dense(ws, Kd.to(dev), torch.full((m,), float(w.sum()) if order == 1 or d == 1 else float(w.sum()) ** d, dtype=D, device=dev), torch.full((m,), 0.1, dtype=D, device=dev))
+        kss = torch.full((m,), float(w.sum()) if order == 1 or d == 1 else float(w.sum()) ** d, dtype=D)
+        rm, rv = orc.posterior_dense(A.detach() - torch.diag(nz), Kr, kss, y, 0.1, nz, 0.1)
+        dp = max(float((pm.cpu() - rm).abs().max()), float((pv.cpu() - rv).abs().max()))
+        worst_k, worst_v, worst_g, worst_p = max(worst_k, dk), max(worst_v, dv), max(worst_g, dg), max(worst_p, dp)
+        if not (dk < 1e-12 and int(out["info"]) == 0 and dv < 1e-9 and dg < 1e-7 and dp < 1e-8):
+            nb += 1
+            print(f"dense: case {c} (n={n} m={m} d={d} q={q} order={order}): K {dk:.3e}, mll {dv:.3e}, dmll/dA {dg:.3e}, posterior {dp:.3e}, info {int(out['info'])}")
+        ws.close()
+    bad += nb
+    print(f"dense: {cases} cases, {nb} outside tolerance; worst |dK| {worst_k:.2e}, |d mll| {worst_v:.2e}, dmll/dA {worst_g:.2e}, posterior {worst_p:.2e}")
 
 sys.exit(1 if bad else 0)
